@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- MLUPS of the fused D2Q9-BGK timestep on MI355X, with roofline and CPU baseline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid NXxNY] [--math exact|fast]
+
+One "step" is one lattice timestep (accelerate_flow + propagate + rebound + collision +
+av_velocity, /root/reference/SerialCode/d2q9-bgk.c:166-170) over the whole grid.  The default
+workload is BASELINE.json's HBM-roofline configuration: the synthetic 8192x8192 grid whose
+obstacle map is the reference's 1024x1024 map tiled 8x8, uniform-equilibrium start (no RNG).
+For N > 1 (launched by torch.distributed.run, one rank per GPU) the SAME grid is row-partitioned
+over the ranks (strong scaling), halo rows travelling by RCCL send/recv inside the engine.
+
+Rank 0 prints ONE JSON line; see the task contract for its keys.  `roofline.achieved` is the
+algorithmic traffic (72 B per lattice update: 9 fp32 reads + 9 fp32 writes) divided by the
+step kernel's device time measured with HIP events on the engine's compute stream.
+"""
+import argparse
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+BYTES_PER_UPDATE = 72.0
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def load_package():
+    spec = importlib.util.spec_from_file_location(
+        "lbm_asynchronous_amd", os.path.join(ROOT, "lbm-asynchronous_amd", "__init__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["lbm_asynchronous_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def synthetic_case(lbm, nx, ny, steps):
+    """params `nx ny iters 10 0.1 0.01 1.85`, obstacles = the reference's
+    1024x1024 map tiled; for the reference's own four grids the matching input files are used."""
+    inputs = os.path.join(ROOT, "tests", "golden", "inputs")
+    own = os.path.join(inputs, f"input_{nx}x{ny}.params")
+    if os.path.exists(own):
+        p = lbm.read_params(own)
+        ob = lbm.read_obstacles(os.path.join(inputs, f"obstacles_{nx}x{ny}.dat"), nx, ny)
+        p.max_iters = steps
+        return p, ob, f"reference data set {nx}x{ny}"
+    tile = lbm.read_obstacles(os.path.join(inputs, "obstacles_1024x1024.dat"), 1024, 1024)
+    ob = lbm.tile_obstacles(tile, nx, ny)
+    p = lbm.Params(nx, ny, steps, 10, 0.1, 0.01, 1.85)
+    return p, ob, f"synthetic {nx}x{ny}: 1024x1024 obstacle map tiled {nx // 1024}x{ny // 1024}"
+
+
+def cpu_baseline(nx, ny, budget_s=20.0):
+    """Time the CPU oracle (kind 'port': oracle/lbm_oracle_cli, single thread, four-sweep AoS form
+    of SerialCode) on a bounded sample of the same workload.  Test infrastructure used as the
+    reported baseline only -- never as the thing measured above."""
+    cli = os.path.join(ROOT, "oracle", "lbm_oracle_cli")
+    if not os.path.exists(cli):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "lbm_oracle_cli"],
+                       capture_output=True)
+    if not os.path.exists(cli):
+        return None
+    # ~30 MLUPS per core for the serial form: pick a step count that fits the budget
+    steps = int(max(2, min(200, budget_s * 30e6 / (nx * ny))))
+    inputs = os.path.join(ROOT, "tests", "golden", "inputs")
+    env = dict(os.environ, LBM_OUTPUT="none", OMP_NUM_THREADS="1")
+    with tempfile.TemporaryDirectory() as tmp:
+        pf = os.path.join(tmp, "in.params")
+        with open(pf, "w") as fh:
+            fh.write(f"{nx}\n{ny}\n{steps}\n10\n0.1\n0.01\n1.85\n")
+        if os.path.exists(os.path.join(inputs, f"obstacles_{nx}x{ny}.dat")):
+            obf = os.path.join(inputs, f"obstacles_{nx}x{ny}.dat")
+        else:
+            obf = os.path.join(inputs, "obstacles_1024x1024.dat")
+            env["LBM_TILE"] = "1024x1024"
+        out = subprocess.run([cli, pf, obf], cwd=tmp, env=env, capture_output=True, text=True)
+    if out.returncode != 0:
+        return None
+    secs = None
+    for line in out.stdout.splitlines():
+        if line.startswith("Elapsed Compute time"):
+            secs = float(line.split()[-2])
+    if not secs:
+        return None
+    return {"value": nx * ny * steps / secs / 1e6, "unit": "MLUPS", "cores": 1, "kind": "port",
+            "sample": f"{steps} steps of the same {nx}x{ny} grid, oracle/lbm_oracle_cli "
+                      f"(four-sweep AoS restatement of SerialCode, gcc -O3, 1 thread), "
+                      f"{secs:.2f} s compute"}
+
+
+def pmc_traffic(nx, ny):
+    """HBM bytes per launch from a committed rocprofv3 --pmc summary, if one matches this grid."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            rec = json.load(fh)
+        return rec.get(f"{nx}x{ny}")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--grid", default="8192x8192")
+    ap.add_argument("--math", default="exact", choices=["exact", "fast"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    nx, ny = (int(v) for v in args.grid.lower().split("x"))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+
+    lbm = load_package()
+    if not os.path.exists(lbm.LIB_PATH):
+        raise SystemExit("liblbm_hip.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+
+    total_steps = args.warmup + args.steps
+    p, ob, workload = synthetic_case(lbm, nx, ny, total_steps)
+
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        uid = [lbm.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        eng = lbm.Engine(p, ob, None, math=args.math, rank=rank, world_size=world,
+                         unique_id=uid[0], device=local_rank)
+    else:
+        eng = lbm.Engine(p, ob, None, n_gpus=1, math=args.math)
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        eng.run(args.warmup)
+    fence()
+    t0 = time.perf_counter()
+    kernel_ms = eng.run_timed(args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    av = eng.av_vels(total_steps)          # forces the cross-rank reduce too
+    finite = bool(np.isfinite(av).all())
+    eng.close()
+
+    if rank == 0:
+        cells = float(nx) * float(ny)
+        mlups = cells * args.steps / elapsed / 1e6
+        # per-launch algorithmic bytes: this rank's share of the grid (max over ranks = ceil)
+        rows_per_rank = -(-ny // world)
+        algo_bytes = BYTES_PER_UPDATE * nx * rows_per_rank
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        traffic = pmc_traffic(nx, ny) if world == 1 else None
+        line = {
+            "metric": "MLUPS", "value": mlups, "unit": "MLUPS (million lattice updates/s)",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"D2Q9-BGK timestep loop, {workload}, uniform-equilibrium start",
+                       "grid": f"{nx}x{ny}", "math": args.math,
+                       "decomposition": f"{world} row slab(s), RCCL halo send/recv" if world > 1
+                       else "single slab, periodic in-kernel"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes},
+            "results_finite": finite,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base = cpu_baseline(nx, ny)
+            if base:
+                line["cpu_baseline"] = base
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,162 @@
+/*
+ * lbm_hip.h -- C-ABI boundary of the MI355X (gfx950) D2Q9-BGK lattice-Boltzmann engine.
+ *
+ * This is the drop-in boundary for the reference's timestep hot path.  The reference
+ * (Xinran1205/LBM-Asynchronous) has no plugin / FFI layer: its boundary is five C functions
+ * called from main()'s loop (SerialCode/d2q9-bgk.c:97-101,113,166-170) over caller-owned host
+ * arrays.  Each entry point below names the reference interface it replaces.
+ *
+ * Plain C types only; no C++ or torch types cross this boundary.  One host thread per context.
+ *
+ * Error behaviour follows the reference: by default an error prints
+ *     "Error at line <n> of file <f>:\n<message>\n"
+ * to stderr and calls exit(EXIT_FAILURE), exactly like die() (SerialCode/d2q9-bgk.c:745-751).
+ * A host that must survive errors (the Python test harness) switches to return codes with
+ * lbm_set_error_mode(LBM_ERRORS_RETURN); functions then return LBM_FAILURE / NULL and
+ * lbm_last_error() holds the message.  There is NO CPU fallback: without a usable HIP device
+ * every compute entry point fails.
+ *
+ * Data layout on the device: structure-of-arrays, 9 planes of fp32, each plane
+ * (rows+2) x pitch with one halo row below and above the owned rows; uint8 obstacle mask.
+ * Host-facing arrays keep the reference's layouts: cells are array-of-structures
+ * (9 consecutive floats per cell, cell index ii + jj*nx, SerialCode/d2q9-bgk.c:78-81),
+ * obstacles are int[ny*nx] with 1 = blocked (:541, :570-601).
+ */
+#ifndef LBM_HIP_H
+#define LBM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LBM_SUCCESS 0
+#define LBM_FAILURE 1
+
+#define LBM_ERRORS_DIE    0 /* reference behaviour: message to stderr + exit(EXIT_FAILURE) */
+#define LBM_ERRORS_RETURN 1 /* return LBM_FAILURE / NULL, message kept for lbm_last_error() */
+
+/* numerics mode of the collision kernel */
+#define LBM_MATH_EXACT 0 /* reference operation order, IEEE / and sqrt, no FMA contraction:
+                            the lattice is bit-identical to SerialCode's */
+#define LBM_MATH_FAST  1 /* reciprocal multiplies + FMA; validated through the check.py rule */
+
+/* Run constants: field-for-field the reference's t_param (SerialCode/d2q9-bgk.c:66-75). */
+typedef struct {
+  int   nx;           /* cells in x */
+  int   ny;           /* cells in y */
+  int   max_iters;    /* iterations (capacity of the av_vels record) */
+  int   reynolds_dim; /* dimension for the Reynolds number */
+  float density;      /* density per link */
+  float accel;        /* density redistribution */
+  float omega;        /* relaxation parameter */
+} lbm_params;
+
+typedef struct lbm_ctx lbm_ctx; /* opaque engine handle */
+
+/* Static facts a host may query (no device needed). */
+typedef struct {
+  int    n_slabs;        /* row slabs this context owns (1 per GPU in single-process mode) */
+  int    row_first;      /* first global row owned by this context */
+  int    row_count;      /* number of global rows owned by this context */
+  int    fluid_cells;    /* GLOBAL number of non-blocked cells (av_velocity's divisor) */
+  int    steps_done;     /* timesteps advanced so far */
+  int    math_mode;      /* LBM_MATH_EXACT or LBM_MATH_FAST */
+  int    world_rank;     /* rank of this context in a multi-process run (0 otherwise) */
+  int    world_size;     /* number of processes sharing the grid (1 otherwise) */
+} lbm_info;
+
+/* ---- error handling -------------------------------------------------------------------- */
+void        lbm_set_error_mode(int mode);
+const char* lbm_last_error(void);
+
+/* ---- library / device probes ------------------------------------------------------------ */
+const char* lbm_version(void);     /* "lbm_hip <ver> gfx950" */
+int         lbm_device_count(void); /* visible HIP devices; 0 when none (never dies) */
+
+/*
+ * Row decomposition used for slabs and ranks (host arithmetic only, no device):
+ * part `index` of `parts` gets rows [*first, *first + *count) of ny.  Balanced blocks,
+ * the first ny % parts parts get one row more.  (The reference's rule,
+ * MPI_Waitall/d2q9-bgk.c:694-704, additionally forces 3 rows onto the last rank because its
+ * acceleration pass runs after the halo rows were posted; here acceleration is fused into the
+ * kernel that produces the row, so no such constraint exists.)  Returns LBM_FAILURE when a
+ * part would own fewer than 2 rows.
+ */
+int lbm_partition_rows(int ny, int parts, int index, int* first, int* count);
+
+/* ---- create / destroy --------------------------------------------------------------------
+ * Replaces the buffer set-up half of initialise() (SerialCode/d2q9-bgk.c:531-567) and
+ * finalise() (:615-634).
+ *
+ * obstacles : int[ny*nx], 1 = blocked (the array initialise() builds, :570-601).
+ * cells_aos : float[ny*nx*9] initial lattice in the reference's AoS layout, or NULL to start
+ *             from the uniform equilibrium of :546-567 generated on the device.
+ * n_gpus    : row slabs / devices to spread the grid over in THIS process (1..8).  Slab g runs
+ *             on device g % lbm_device_count(); several slabs may share one device (used to
+ *             test the halo path on a 1-GPU box).
+ * math_mode : LBM_MATH_EXACT or LBM_MATH_FAST.
+ */
+lbm_ctx* lbm_create(const lbm_params* params, const int* obstacles, const float* cells_aos,
+                    int n_gpus, int math_mode);
+
+/*
+ * One-process-per-GPU form (torchrun / RANK, WORLD_SIZE): this process owns the rows
+ * lbm_partition_rows(ny, world_size, rank) of the global grid on HIP device `device`;
+ * halo rows travel by RCCL send/recv (the GPU analogue of MPI_Isend/Irecv + Waitall,
+ * MPI_Waitall/d2q9-bgk.c:225-243).  `unique_id` is the 128-byte RCCL id obtained by rank 0
+ * from lbm_rccl_unique_id() and broadcast by the host (e.g. over torch.distributed).
+ * obstacles is the GLOBAL mask (every rank parses the same file), cells_aos the GLOBAL
+ * initial lattice or NULL.
+ */
+#define LBM_RCCL_ID_BYTES 128
+int      lbm_rccl_unique_id(void* id_out);
+lbm_ctx* lbm_create_rank(const lbm_params* params, const int* obstacles, const float* cells_aos,
+                         int rank, int world_size, const void* unique_id, int device,
+                         int math_mode);
+
+void     lbm_destroy(lbm_ctx* ctx);
+int      lbm_get_info(const lbm_ctx* ctx, lbm_info* out);
+
+/* ---- the hot path ------------------------------------------------------------------------
+ * lbm_run replaces n_steps trips of the driver loop (SerialCode/d2q9-bgk.c:166-170):
+ *     timestep(params, cells, tmp_cells, obstacles);      // accelerate_flow, propagate,
+ *                                                         // rebound, collision  (:207-407)
+ *     av_vels[tt] = av_velocity(params, cells, obstacles); // (:409-458)
+ * with no host round trip per step.  Per-step sums of |u| accumulate on the device.
+ * lbm_sync waits for the device (call it before reading the clock, as the reference's
+ * "Elapsed Compute time" brackets the loop, :162-185).
+ */
+int lbm_run(lbm_ctx* ctx, int n_steps);
+int lbm_sync(lbm_ctx* ctx);
+
+/*
+ * Same as lbm_run, additionally timing the step kernels with HIP events recorded on the
+ * stream(s) the kernels are launched on.  *kernel_ms_per_step receives the average device
+ * time of one timestep (max over slabs).
+ */
+int lbm_run_timed(lbm_ctx* ctx, int n_steps, float* kernel_ms_per_step);
+
+/* ---- results -----------------------------------------------------------------------------
+ * lbm_read_av_vels: out[t] = tot_u[t] / (float)fluid_cells for the first n recorded steps
+ *   (the values main() stores at SerialCode/d2q9-bgk.c:169; fp32 division as :457).
+ *   In a multi-process context the per-rank sums are first all-reduced (the reference's
+ *   MPI_Reduce, MPI/d2q9-bgk.c:298-309); every rank receives the result.
+ * lbm_read_cells: the owned rows of the lattice in the reference's AoS layout, so that
+ *   write_values()/calc_reynolds() logic (:637-642, :662-743) can run on it unchanged.
+ * lbm_read_final_state: u_x, u_y, |u|, pressure of the owned rows computed on the device
+ *   with the formulas of write_values() (:684-719); blocked cells give 0,0,0,density*c_sq.
+ * lbm_av_velocity: av_velocity() of the current lattice (:409-458) -- what calc_reynolds()
+ *   (:637-642) multiplies; lbm_total_density: total_density() (:644-660).
+ *   Both are global (all slabs / all ranks).
+ */
+int   lbm_read_av_vels(lbm_ctx* ctx, float* out, int n);
+int   lbm_read_cells(lbm_ctx* ctx, float* cells_aos);
+int   lbm_read_final_state(lbm_ctx* ctx, float* u_x, float* u_y, float* u_mag, float* pressure);
+int   lbm_av_velocity(lbm_ctx* ctx, float* out);
+int   lbm_total_density(lbm_ctx* ctx, double* out);
+int   lbm_calc_reynolds(lbm_ctx* ctx, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LBM_HIP_H */

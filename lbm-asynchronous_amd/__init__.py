@@ -1,0 +1,340 @@
+"""Python host-side binding of the MI355X D2Q9-BGK engine (ctypes over the C ABI).
+
+The directory name carries a hyphen (it mirrors the reference repository's name), so load it
+with :func:`importlib` -- ``tests/conftest.py`` and ``bench.py`` do::
+
+    spec = importlib.util.spec_from_file_location("lbm_asynchronous_amd", ".../__init__.py")
+
+Everything here is plumbing around ``liblbm_hip.so`` (``include/lbm_hip.h``): numpy arrays in the
+reference's host layouts go in, numpy arrays come out.  There is no Python or CPU compute path;
+if the shared library is missing or no HIP device is usable, calls raise :class:`LbmError`.
+
+Reference interfaces mirrored (``/root/reference/SerialCode/d2q9-bgk.c``):
+``t_param`` (:66-75) -> :class:`Params`; ``initialise`` file formats (:460-613) ->
+:func:`read_params`, :func:`read_obstacles`; the ``timestep``/``av_velocity`` loop (:166-170) ->
+:meth:`Engine.run`; ``write_values`` (:662-743) -> :func:`write_final_state`, :func:`write_av_vels`.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblbm_hip.so")
+CLI_PATH = os.path.join(_HERE, "d2q9-bgk")
+
+MATH_EXACT = 0
+MATH_FAST = 1
+_MATH = {"exact": MATH_EXACT, "fast": MATH_FAST, MATH_EXACT: MATH_EXACT, MATH_FAST: MATH_FAST}
+RCCL_ID_BYTES = 128
+
+# every symbol include/lbm_hip.h declares (tests check the .so exports them all)
+ABI_SYMBOLS = (
+    "lbm_set_error_mode", "lbm_last_error", "lbm_version", "lbm_device_count",
+    "lbm_partition_rows", "lbm_create", "lbm_rccl_unique_id", "lbm_create_rank", "lbm_destroy",
+    "lbm_get_info", "lbm_run", "lbm_sync", "lbm_run_timed", "lbm_read_av_vels", "lbm_read_cells",
+    "lbm_read_final_state", "lbm_av_velocity", "lbm_total_density", "lbm_calc_reynolds",
+)
+
+
+class LbmError(RuntimeError):
+    pass
+
+
+class _CParams(ctypes.Structure):
+    _fields_ = [("nx", ctypes.c_int), ("ny", ctypes.c_int), ("max_iters", ctypes.c_int),
+                ("reynolds_dim", ctypes.c_int), ("density", ctypes.c_float),
+                ("accel", ctypes.c_float), ("omega", ctypes.c_float)]
+
+
+class _CInfo(ctypes.Structure):
+    _fields_ = [("n_slabs", ctypes.c_int), ("row_first", ctypes.c_int), ("row_count", ctypes.c_int),
+                ("fluid_cells", ctypes.c_int), ("steps_done", ctypes.c_int),
+                ("math_mode", ctypes.c_int), ("world_rank", ctypes.c_int),
+                ("world_size", ctypes.c_int)]
+
+
+@dataclass
+class Params:
+    """The reference's t_param (SerialCode/d2q9-bgk.c:66-75)."""
+    nx: int
+    ny: int
+    max_iters: int
+    reynolds_dim: int
+    density: float
+    accel: float
+    omega: float
+
+    def _c(self) -> _CParams:
+        return _CParams(self.nx, self.ny, self.max_iters, self.reynolds_dim,
+                        self.density, self.accel, self.omega)
+
+
+# ------------------------------------------------------------------------------------------------
+# building and loading the shared library
+# ------------------------------------------------------------------------------------------------
+def build(force: bool = False) -> None:
+    """Compile liblbm_hip.so (gfx950) and the d2q9-bgk host program in-tree with make."""
+    cmd = ["make", "-C", _HERE] + (["-B"] if force else [])
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    if out.returncode != 0:
+        raise LbmError("building liblbm_hip.so failed:\n" + out.stdout + out.stderr)
+
+
+_lib = None
+
+
+def load_library() -> ctypes.CDLL:
+    """dlopen liblbm_hip.so and declare the C-ABI prototypes.  Fails loudly if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LbmError(f"{LIB_PATH} not built: run `make -C {_HERE}` (no fallback path exists)")
+    lib = ctypes.CDLL(LIB_PATH)
+    P, I, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    PF, PI = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)
+    lib.lbm_set_error_mode.argtypes = [I]; lib.lbm_set_error_mode.restype = None
+    lib.lbm_last_error.argtypes = []; lib.lbm_last_error.restype = ctypes.c_char_p
+    lib.lbm_version.argtypes = []; lib.lbm_version.restype = ctypes.c_char_p
+    lib.lbm_device_count.argtypes = []; lib.lbm_device_count.restype = I
+    lib.lbm_partition_rows.argtypes = [I, I, I, PI, PI]; lib.lbm_partition_rows.restype = I
+    lib.lbm_create.argtypes = [ctypes.POINTER(_CParams), P, P, I, I]; lib.lbm_create.restype = P
+    lib.lbm_rccl_unique_id.argtypes = [P]; lib.lbm_rccl_unique_id.restype = I
+    lib.lbm_create_rank.argtypes = [ctypes.POINTER(_CParams), P, P, I, I, P, I, I]
+    lib.lbm_create_rank.restype = P
+    lib.lbm_destroy.argtypes = [P]; lib.lbm_destroy.restype = None
+    lib.lbm_get_info.argtypes = [P, ctypes.POINTER(_CInfo)]; lib.lbm_get_info.restype = I
+    lib.lbm_run.argtypes = [P, I]; lib.lbm_run.restype = I
+    lib.lbm_sync.argtypes = [P]; lib.lbm_sync.restype = I
+    lib.lbm_run_timed.argtypes = [P, I, PF]; lib.lbm_run_timed.restype = I
+    lib.lbm_read_av_vels.argtypes = [P, P, I]; lib.lbm_read_av_vels.restype = I
+    lib.lbm_read_cells.argtypes = [P, P]; lib.lbm_read_cells.restype = I
+    lib.lbm_read_final_state.argtypes = [P, P, P, P, P]; lib.lbm_read_final_state.restype = I
+    lib.lbm_av_velocity.argtypes = [P, PF]; lib.lbm_av_velocity.restype = I
+    lib.lbm_total_density.argtypes = [P, ctypes.POINTER(ctypes.c_double)]
+    lib.lbm_total_density.restype = I
+    lib.lbm_calc_reynolds.argtypes = [P, PF]; lib.lbm_calc_reynolds.restype = I
+    # a Python host wants exceptions, not exit(): switch from the reference's die() behaviour
+    lib.lbm_set_error_mode(1)
+    _lib = lib
+    return lib
+
+
+def _check(lib, rc) -> None:
+    if rc != 0:
+        raise LbmError(lib.lbm_last_error().decode())
+
+
+def device_count() -> int:
+    return int(load_library().lbm_device_count())
+
+
+def partition_rows(ny: int, parts: int, index: int) -> tuple[int, int]:
+    """Rows [first, first+count) owned by part `index` of `parts` (lbm_partition_rows)."""
+    lib = load_library()
+    first, count = ctypes.c_int(), ctypes.c_int()
+    _check(lib, lib.lbm_partition_rows(ny, parts, index, ctypes.byref(first), ctypes.byref(count)))
+    return first.value, count.value
+
+
+def rccl_unique_id() -> bytes:
+    lib = load_library()
+    buf = ctypes.create_string_buffer(RCCL_ID_BYTES)
+    _check(lib, lib.lbm_rccl_unique_id(buf))
+    return buf.raw
+
+
+# ------------------------------------------------------------------------------------------------
+# the engine handle
+# ------------------------------------------------------------------------------------------------
+class Engine:
+    """One lattice on one or more GPUs.  Mirrors the reference's main()-level use of the hot path:
+    create (initialise), run (the timestep/av_velocity loop), read results, close (finalise)."""
+
+    def __init__(self, params: Params, obstacles: np.ndarray, cells: np.ndarray | None = None,
+                 n_gpus: int = 1, math: str | int = "exact", *, rank: int | None = None,
+                 world_size: int | None = None, unique_id: bytes | None = None, device: int = 0):
+        self.lib = load_library()
+        self.params = params
+        obstacles = np.ascontiguousarray(obstacles, dtype=np.int32).reshape(params.ny, params.nx)
+        self._obstacles = obstacles
+        cptr = None
+        if cells is not None:
+            cells = np.ascontiguousarray(cells, dtype=np.float32).reshape(params.ny, params.nx, 9)
+            cptr = cells.ctypes.data
+        cp = params._c()
+        if rank is None:
+            h = self.lib.lbm_create(ctypes.byref(cp), obstacles.ctypes.data, cptr, n_gpus, _MATH[math])
+        else:
+            idbuf = ctypes.create_string_buffer(unique_id, RCCL_ID_BYTES) if unique_id else None
+            h = self.lib.lbm_create_rank(ctypes.byref(cp), obstacles.ctypes.data, cptr, rank,
+                                         world_size, idbuf, device, _MATH[math])
+        if not h:
+            raise LbmError(self.lib.lbm_last_error().decode())
+        self.handle = ctypes.c_void_p(h)
+
+    # -- lifecycle ---------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.lbm_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self) -> dict:
+        ci = _CInfo()
+        _check(self.lib, self.lib.lbm_get_info(self.handle, ctypes.byref(ci)))
+        return {name: getattr(ci, name) for name, _ in _CInfo._fields_}
+
+    # -- hot path ----------------------------------------------------------------------------
+    def run(self, n_steps: int) -> None:
+        _check(self.lib, self.lib.lbm_run(self.handle, int(n_steps)))
+
+    def run_timed(self, n_steps: int) -> float:
+        """Advance n_steps; returns the average device milliseconds per step (HIP events on the
+        compute stream)."""
+        ms = ctypes.c_float()
+        _check(self.lib, self.lib.lbm_run_timed(self.handle, int(n_steps), ctypes.byref(ms)))
+        return float(ms.value)
+
+    def sync(self) -> None:
+        _check(self.lib, self.lib.lbm_sync(self.handle))
+
+    # -- results -----------------------------------------------------------------------------
+    def av_vels(self, n: int | None = None) -> np.ndarray:
+        n = self.info()["steps_done"] if n is None else n
+        out = np.empty(n, dtype=np.float32)
+        _check(self.lib, self.lib.lbm_read_av_vels(self.handle, out.ctypes.data, n))
+        return out
+
+    def cells(self) -> np.ndarray:
+        """Owned rows of the lattice in the reference's AoS layout: (rows, nx, 9) float32."""
+        rows = self.info()["row_count"]
+        out = np.empty((rows, self.params.nx, 9), dtype=np.float32)
+        _check(self.lib, self.lib.lbm_read_cells(self.handle, out.ctypes.data))
+        return out
+
+    def final_state(self) -> dict:
+        rows = self.info()["row_count"]
+        shape = (rows, self.params.nx)
+        f = {k: np.empty(shape, dtype=np.float32) for k in ("u_x", "u_y", "u", "pressure")}
+        _check(self.lib, self.lib.lbm_read_final_state(
+            self.handle, f["u_x"].ctypes.data, f["u_y"].ctypes.data, f["u"].ctypes.data,
+            f["pressure"].ctypes.data))
+        return f
+
+    def av_velocity(self) -> float:
+        v = ctypes.c_float()
+        _check(self.lib, self.lib.lbm_av_velocity(self.handle, ctypes.byref(v)))
+        return float(v.value)
+
+    def total_density(self) -> float:
+        v = ctypes.c_double()
+        _check(self.lib, self.lib.lbm_total_density(self.handle, ctypes.byref(v)))
+        return float(v.value)
+
+    def reynolds(self) -> float:
+        v = ctypes.c_float()
+        _check(self.lib, self.lib.lbm_calc_reynolds(self.handle, ctypes.byref(v)))
+        return float(v.value)
+
+
+# ------------------------------------------------------------------------------------------------
+# file formats of the command line (Python twins of host/lbm_io.c, for tests and bench.py)
+# ------------------------------------------------------------------------------------------------
+def read_params(path: str) -> Params:
+    """7 whitespace-separated values, fixed order (SerialCode/d2q9-bgk.c:480-506)."""
+    with open(path) as fh:
+        tok = fh.read().split()
+    names = ("nx", "ny", "maxIters", "reynolds_dim", "density", "accel", "omega")
+    if len(tok) < 7:
+        raise LbmError(f"could not read param file: {names[len(tok)]}")
+    try:
+        return Params(int(tok[0]), int(tok[1]), int(tok[2]), int(tok[3]),
+                      float(tok[4]), float(tok[5]), float(tok[6]))
+    except ValueError as exc:
+        raise LbmError(f"could not read param file: {exc}") from None
+
+
+def read_obstacles(path: str, nx: int, ny: int) -> np.ndarray:
+    """'x y 1' lines -> int32 (ny, nx) map; the reference's range checks (:590-597)."""
+    grid = np.zeros((ny, nx), dtype=np.int32)
+    with open(path) as fh:
+        tok = fh.read().split()
+    if len(tok) % 3:
+        raise LbmError("expected 3 values per line in obstacle file")
+    try:
+        arr = np.array(tok, dtype=np.int64).reshape(-1, 3)
+    except ValueError:
+        raise LbmError("expected 3 values per line in obstacle file") from None
+    if arr.size:
+        if (arr[:, 0] < 0).any() or (arr[:, 0] > nx - 1).any():
+            raise LbmError("obstacle x-coord out of range")
+        if (arr[:, 1] < 0).any() or (arr[:, 1] > ny - 1).any():
+            raise LbmError("obstacle y-coord out of range")
+        if (arr[:, 2] != 1).any():
+            raise LbmError("obstacle blocked value should be 1")
+        grid[arr[:, 1], arr[:, 0]] = 1
+    return grid
+
+
+def tile_obstacles(tile: np.ndarray, nx: int, ny: int) -> np.ndarray:
+    """Synthetic large grids: repeat a small map periodically."""
+    ty, tx = tile.shape
+    reps = (-(-ny // ty), -(-nx // tx))
+    return np.ascontiguousarray(np.tile(tile, reps)[:ny, :nx], dtype=np.int32)
+
+
+def write_av_vels(path: str, av_vels: np.ndarray) -> None:
+    """'%d:\\t%.12E\\n' (SerialCode/d2q9-bgk.c:735-738)."""
+    with open(path, "w") as fh:
+        for i, v in enumerate(np.asarray(av_vels, dtype=np.float32)):
+            fh.write("%d:\t%.12E\n" % (i, float(v)))
+
+
+def write_final_state(path: str, fields: dict, obstacles: np.ndarray) -> None:
+    """'%d %d %.12E %.12E %.12E %.12E %d\\n', jj outer / ii inner (:679-723)."""
+    ny, nx = obstacles.shape
+    with open(path, "w") as fh:
+        for jj in range(ny):
+            ux, uy, u, pr, ob = (fields["u_x"][jj], fields["u_y"][jj], fields["u"][jj],
+                                 fields["pressure"][jj], obstacles[jj])
+            fh.write("".join("%d %d %.12E %.12E %.12E %.12E %d\n" %
+                             (ii, jj, ux[ii], uy[ii], u[ii], pr[ii], ob[ii]) for ii in range(nx)))
+
+
+# ------------------------------------------------------------------------------------------------
+# the acceptance rule of the reference's check/check.py (:83-99, :136-148)
+# ------------------------------------------------------------------------------------------------
+def check_rule(ref: np.ndarray, sim: np.ndarray) -> dict:
+    """max over entries of 100*(ref-sim)/sim, as check.py computes it (diff/(ref-diff))."""
+    ref = np.asarray(ref, dtype=np.float64).ravel()
+    sim = np.asarray(sim, dtype=np.float64).ravel()
+    if ref.size != sim.size:
+        raise LbmError("Different number of steps in av_vels files")
+    diff = ref - sim
+    with np.errstate(divide="ignore", invalid="ignore"):
+        pct = 100.0 * (diff / (ref - diff))
+    k = int(np.argmax(np.abs(pct)))
+    return {"index": k, "max_diff": float(diff[k]), "max_diff_pcnt": float(pct[k]),
+            "sim_val": float(sim[k]), "ref_val": float(ref[k]), "total": float(np.abs(diff).sum())}
+
+
+def check_passes(ref: np.ndarray, sim: np.ndarray, tolerance_pct: float = 1.0) -> bool:
+    d = check_rule(ref, sim)
+    return bool(np.isfinite(d["max_diff_pcnt"]) and abs(d["max_diff_pcnt"]) <= tolerance_pct)

@@ -1,0 +1,770 @@
+// lbm_hip.hip -- host side of the C-ABI engine declared in include/lbm_hip.h.
+//
+// Owns the device lattices (row slabs, one per GPU), the per-step launch sequence, the halo
+// exchange (RCCL send/recv on a side stream, overlapped with the interior rows -- the GPU
+// analogue of /root/reference/MPI_Waitall/d2q9-bgk.c:225-253) and the result read-back.
+// No CPU compute path exists here: without a HIP device every compute entry point fails.
+#include "../../include/lbm_hip.h"
+#include "lbm_kernels.hip.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+constexpr int kMaxSlabs = 8;
+constexpr int kPartSlots = 64;  // steps whose partial sums are buffered before one reduce launch
+
+enum HaloMode { HALO_SELF = 0, HALO_MEMCPY = 1, HALO_RCCL = 2 };
+
+// ---- error handling (reference: die(), SerialCode/d2q9-bgk.c:745-751) -----------------------
+int g_error_mode = LBM_ERRORS_DIE;
+thread_local char g_last_error[1024] = "";
+
+void raise_error(int line, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+  va_end(ap);
+  if (g_error_mode == LBM_ERRORS_DIE) {
+    fprintf(stderr, "Error at line %d of file %s:\n", line, __FILE__);
+    fprintf(stderr, "%s\n", g_last_error);
+    fflush(stderr);
+    exit(EXIT_FAILURE);
+  }
+}
+
+#define LBM_FAIL(ret, ...)              \
+  do {                                  \
+    raise_error(__LINE__, __VA_ARGS__); \
+    return ret;                         \
+  } while (0)
+
+#define HIP_TRY(ret, expr)                                                              \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) LBM_FAIL(ret, "HIP error: %s (%s)", hipGetErrorString(e_), #expr); \
+  } while (0)
+
+#define NCCL_TRY(ret, expr)                                                               \
+  do {                                                                                    \
+    ncclResult_t r_ = (expr);                                                             \
+    if (r_ != ncclSuccess) LBM_FAIL(ret, "RCCL error: %s (%s)", ncclGetErrorString(r_), #expr); \
+  } while (0)
+
+inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+inline long round_up(long a, long b) { return (a + b - 1) / b * b; }
+
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+struct Slab {
+  int device = 0;
+  int row_first = 0;  // global row of slab row 0
+  int rows = 0;       // owned rows
+  int accel_row = -1; // slab row holding global row ny-2, or -1
+  float* lat[2] = {nullptr, nullptr};
+  unsigned char* mask = nullptr;
+  float* partials = nullptr;  // kPartSlots x part_stride
+  double* tot_u = nullptr;    // capacity entries: per-step sum of |u| over this slab
+  double* scratch = nullptr;  // 2 x kSumBlocks doubles for lattice_sums
+  float* send_south = nullptr;  // 3 x pitch each
+  float* send_north = nullptr;
+  float* recv_south = nullptr;
+  float* recv_north = nullptr;
+  hipStream_t compute = nullptr, comm = nullptr;
+  hipEvent_t ev_boundary = nullptr, ev_halo = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+  ncclComm_t nccl = nullptr;
+  int blocks_main = 0;      // interior rows (or all rows in HALO_SELF)
+  int blocks_boundary = 0;  // rows 0 and rows-1 (halo modes)
+};
+
+constexpr int kSumBlocks = 1024;
+
+}  // namespace
+
+struct lbm_ctx {
+  lbm_params p;
+  int pitch = 0;
+  long plane_stride[kMaxSlabs] = {0};
+  int n_slabs = 0;
+  Slab slab[kMaxSlabs];
+  int cur = 0;  // lattice holding the current state
+  int steps_done = 0;
+  int capacity = 0;  // entries in tot_u
+  int fluid_cells = 0;
+  int math_mode = LBM_MATH_EXACT;
+  int halo = HALO_SELF;
+  int rank = 0, world = 1;  // multi-process
+  int row_first = 0, row_count = 0;
+  int slot_fill = 0;  // partial slots used since the last reduce
+  long part_stride = 0;
+  bool vec4 = false;
+};
+
+namespace {
+
+// ---- launch helpers --------------------------------------------------------------------------
+int launch_step(lbm_ctx* c, int s, int row_first, int row_stride, int n_rows, int part_offset,
+                bool accel_epilogue) {
+  Slab& sl = c->slab[s];
+  if (n_rows <= 0) return LBM_SUCCESS;
+  lbm::StepArgs a;
+  a.src = sl.lat[c->cur];
+  a.dst = sl.lat[c->cur ^ 1];
+  a.mask = sl.mask;
+  a.plane_stride = c->plane_stride[s];
+  a.pitch = c->pitch;
+  a.nx = c->p.nx;
+  a.rows = sl.rows;
+  a.row_first = row_first;
+  a.row_stride = row_stride;
+  a.n_rows = n_rows;
+  a.accel_row = accel_epilogue ? sl.accel_row : -1;
+  a.omega = c->p.omega;
+  a.a1 = c->p.density * c->p.accel / 9.f;   // SerialCode/d2q9-bgk.c:219
+  a.a2 = c->p.density * c->p.accel / 36.f;  // :220
+  a.partials = sl.partials + (long)c->slot_fill * c->part_stride + part_offset;
+  const bool halo = (c->halo != HALO_SELF);
+  a.recv_south = halo ? sl.recv_south : nullptr;
+  a.recv_north = halo ? sl.recv_north : nullptr;
+  a.send_south = halo ? sl.send_south : nullptr;
+  a.send_north = halo ? sl.send_north : nullptr;
+
+  const bool exact = (c->math_mode == LBM_MATH_EXACT);
+  if (c->vec4) {
+    const int blocks = ceil_div((long)(c->p.nx / 4) * n_rows, lbm::kBlock);
+    if (exact) hipLaunchKernelGGL(lbm::step_vec4<true>, dim3(blocks), dim3(lbm::kBlock), 0, sl.compute, a);
+    else       hipLaunchKernelGGL(lbm::step_vec4<false>, dim3(blocks), dim3(lbm::kBlock), 0, sl.compute, a);
+  } else {
+    const int blocks = ceil_div((long)c->p.nx * n_rows, lbm::kBlock);
+    if (exact) hipLaunchKernelGGL(lbm::step_scalar<true>, dim3(blocks), dim3(lbm::kBlock), 0, sl.compute, a);
+    else       hipLaunchKernelGGL(lbm::step_scalar<false>, dim3(blocks), dim3(lbm::kBlock), 0, sl.compute, a);
+  }
+  HIP_TRY(LBM_FAILURE, hipGetLastError());
+  return LBM_SUCCESS;
+}
+
+int blocks_for_rows(const lbm_ctx* c, int n_rows) {
+  if (n_rows <= 0) return 0;
+  return c->vec4 ? ceil_div((long)(c->p.nx / 4) * n_rows, lbm::kBlock)
+                 : ceil_div((long)c->p.nx * n_rows, lbm::kBlock);
+}
+
+// One halo exchange: every slab's packed send rows travel to its ring neighbours' recv rows.
+// north neighbour of slab s = s+1 (periodic), south = s-1; across processes the ring runs over
+// ranks (MPI/d2q9-bgk.c:210-211).
+int exchange_halos(lbm_ctx* c) {
+  const long n = 3L * c->pitch;
+  if (c->halo == HALO_RCCL) {
+    // comm stream waits for the boundary kernel that filled the send rows
+    for (int s = 0; s < c->n_slabs; s++) {
+      Slab& sl = c->slab[s];
+      HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+      HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sl.ev_boundary, 0));
+    }
+    NCCL_TRY(LBM_FAILURE, ncclGroupStart());
+    for (int s = 0; s < c->n_slabs; s++) {
+      Slab& sl = c->slab[s];
+      int me, parts;
+      if (c->world > 1) { me = c->rank; parts = c->world; } else { me = s; parts = c->n_slabs; }
+      const int north = (me + 1) % parts, south = (me - 1 + parts) % parts;
+      // order matters when north == south (2 parts): first send pairs with the peer's first recv
+      NCCL_TRY(LBM_FAILURE, ncclSend(sl.send_north, n, ncclFloat, north, sl.nccl, sl.comm));
+      NCCL_TRY(LBM_FAILURE, ncclSend(sl.send_south, n, ncclFloat, south, sl.nccl, sl.comm));
+      NCCL_TRY(LBM_FAILURE, ncclRecv(sl.recv_south, n, ncclFloat, south, sl.nccl, sl.comm));
+      NCCL_TRY(LBM_FAILURE, ncclRecv(sl.recv_north, n, ncclFloat, north, sl.nccl, sl.comm));
+    }
+    NCCL_TRY(LBM_FAILURE, ncclGroupEnd());
+    for (int s = 0; s < c->n_slabs; s++) {
+      Slab& sl = c->slab[s];
+      HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+      HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_halo, sl.comm));
+    }
+  } else if (c->halo == HALO_MEMCPY) {
+    // push model inside one process: slab s copies its send rows into its neighbours' recv rows.
+    // It may do so once its own boundary kernel (send rows written) and the neighbours' boundary
+    // kernels (their recv rows consumed) have finished.
+    for (int s = 0; s < c->n_slabs; s++) {
+      Slab& sl = c->slab[s];
+      const int north = (s + 1) % c->n_slabs, south = (s - 1 + c->n_slabs) % c->n_slabs;
+      HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+      HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sl.ev_boundary, 0));
+      HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, c->slab[north].ev_boundary, 0));
+      HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, c->slab[south].ev_boundary, 0));
+      HIP_TRY(LBM_FAILURE, hipMemcpyAsync(c->slab[north].recv_south, sl.send_north, n * sizeof(float),
+                                          hipMemcpyDefault, sl.comm));
+      HIP_TRY(LBM_FAILURE, hipMemcpyAsync(c->slab[south].recv_north, sl.send_south, n * sizeof(float),
+                                          hipMemcpyDefault, sl.comm));
+      HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_halo, sl.comm));
+    }
+  }
+  return LBM_SUCCESS;
+}
+
+// the compute stream of slab s must not start its boundary rows before the halos have landed
+int wait_halos(lbm_ctx* c, int s) {
+  Slab& sl = c->slab[s];
+  HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, sl.ev_halo, 0));
+  if (c->halo == HALO_MEMCPY) {
+    const int north = (s + 1) % c->n_slabs, south = (s - 1 + c->n_slabs) % c->n_slabs;
+    HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, c->slab[north].ev_halo, 0));
+    HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, c->slab[south].ev_halo, 0));
+  }
+  return LBM_SUCCESS;
+}
+
+// reduce the buffered per-workgroup partials of the last slot_fill steps into tot_u[step_base...]
+int flush_partials(lbm_ctx* c, int step_base) {
+  if (c->slot_fill == 0) return LBM_SUCCESS;
+  for (int s = 0; s < c->n_slabs; s++) {
+    Slab& sl = c->slab[s];
+    HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+    hipLaunchKernelGGL(lbm::reduce_partials, dim3(c->slot_fill), dim3(lbm::kBlock), 0, sl.compute,
+                       sl.partials, sl.blocks_main + sl.blocks_boundary, c->part_stride, sl.tot_u,
+                       step_base);
+    HIP_TRY(LBM_FAILURE, hipGetLastError());
+  }
+  return LBM_SUCCESS;
+}
+
+int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
+  if (!c) LBM_FAIL(LBM_FAILURE, "lbm_run: null context");
+  if (n_steps < 0) LBM_FAIL(LBM_FAILURE, "lbm_run: negative step count");
+  if (kernel_ms) *kernel_ms = 0.f;
+  if (n_steps == 0) return LBM_SUCCESS;
+  if (c->steps_done + n_steps > c->capacity)
+    LBM_FAIL(LBM_FAILURE, "lbm_run: %d steps requested but the av_vels record holds %d (maxIters)",
+             c->steps_done + n_steps, c->capacity);
+
+  const float a1 = c->p.density * c->p.accel / 9.f;
+  const float a2 = c->p.density * c->p.accel / 36.f;
+  const bool halo = (c->halo != HALO_SELF);
+
+  // accelerate_flow() of the first step (later steps: epilogue of the step kernel)
+  for (int s = 0; s < c->n_slabs; s++) {
+    Slab& sl = c->slab[s];
+    HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+    if (sl.accel_row >= 0) {
+      hipLaunchKernelGGL(lbm::accelerate_row, dim3(ceil_div(c->p.nx, 256)), dim3(256), 0, sl.compute,
+                         sl.lat[c->cur], sl.mask, c->plane_stride[s], c->pitch, c->p.nx, sl.accel_row,
+                         a1, a2);
+      HIP_TRY(LBM_FAILURE, hipGetLastError());
+    }
+    if (halo) {
+      hipLaunchKernelGGL(lbm::pack_halo, dim3(ceil_div(c->p.nx, 256)), dim3(256), 0, sl.compute,
+                         sl.lat[c->cur], c->plane_stride[s], c->pitch, c->p.nx, sl.rows, sl.send_south,
+                         sl.send_north);
+      HIP_TRY(LBM_FAILURE, hipGetLastError());
+      HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_boundary, sl.compute));
+    }
+  }
+  if (halo && exchange_halos(c) != LBM_SUCCESS) return LBM_FAILURE;
+
+  if (kernel_ms)
+    for (int s = 0; s < c->n_slabs; s++) {
+      HIP_TRY(LBM_FAILURE, hipSetDevice(c->slab[s].device));
+      HIP_TRY(LBM_FAILURE, hipEventRecord(c->slab[s].ev_t0, c->slab[s].compute));
+    }
+
+  int flushed_upto = c->steps_done;
+  for (int t = 0; t < n_steps; t++) {
+    const bool last = (t == n_steps - 1);
+    for (int s = 0; s < c->n_slabs; s++) {
+      Slab& sl = c->slab[s];
+      HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+      if (!halo) {
+        if (launch_step(c, s, 0, 1, sl.rows, 0, !last) != LBM_SUCCESS) return LBM_FAILURE;
+      } else {
+        // interior rows need no halo: they overlap with the exchange in flight
+        if (launch_step(c, s, 1, 1, sl.rows - 2, 0, !last) != LBM_SUCCESS) return LBM_FAILURE;
+      }
+    }
+    if (halo) {
+      for (int s = 0; s < c->n_slabs; s++) {
+        Slab& sl = c->slab[s];
+        HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+        if (wait_halos(c, s) != LBM_SUCCESS) return LBM_FAILURE;
+        // boundary rows 0 and rows-1 (the Waitall-then-boundary pattern,
+        // MPI_Waitall/d2q9-bgk.c:243-253)
+        if (launch_step(c, s, 0, sl.rows - 1, 2, sl.blocks_main, !last) != LBM_SUCCESS) return LBM_FAILURE;
+        HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_boundary, sl.compute));
+      }
+      if (!last && exchange_halos(c) != LBM_SUCCESS) return LBM_FAILURE;
+    }
+    c->cur ^= 1;
+    c->slot_fill++;
+    if (c->slot_fill == kPartSlots || last) {
+      if (flush_partials(c, flushed_upto) != LBM_SUCCESS) return LBM_FAILURE;
+      flushed_upto += c->slot_fill;
+      c->slot_fill = 0;
+    }
+  }
+  c->steps_done += n_steps;
+
+  if (kernel_ms) {
+    float worst = 0.f;
+    for (int s = 0; s < c->n_slabs; s++) {
+      Slab& sl = c->slab[s];
+      HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+      HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_t1, sl.compute));
+    }
+    for (int s = 0; s < c->n_slabs; s++) {
+      Slab& sl = c->slab[s];
+      HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+      HIP_TRY(LBM_FAILURE, hipEventSynchronize(sl.ev_t1));
+      float ms = 0.f;
+      HIP_TRY(LBM_FAILURE, hipEventElapsedTime(&ms, sl.ev_t0, sl.ev_t1));
+      if (ms > worst) worst = ms;
+    }
+    *kernel_ms = worst / (float)n_steps;
+  }
+  return LBM_SUCCESS;
+}
+
+void free_slab(Slab& sl) {
+  if (hipSetDevice(sl.device) != hipSuccess) return;
+  if (sl.nccl) ncclCommDestroy(sl.nccl);
+  for (int i = 0; i < 2; i++) if (sl.lat[i]) (void)hipFree(sl.lat[i]);
+  if (sl.mask) (void)hipFree(sl.mask);
+  if (sl.partials) (void)hipFree(sl.partials);
+  if (sl.tot_u) (void)hipFree(sl.tot_u);
+  if (sl.scratch) (void)hipFree(sl.scratch);
+  if (sl.send_south) (void)hipFree(sl.send_south);
+  if (sl.send_north) (void)hipFree(sl.send_north);
+  if (sl.recv_south) (void)hipFree(sl.recv_south);
+  if (sl.recv_north) (void)hipFree(sl.recv_north);
+  if (sl.ev_boundary) (void)hipEventDestroy(sl.ev_boundary);
+  if (sl.ev_halo) (void)hipEventDestroy(sl.ev_halo);
+  if (sl.ev_t0) (void)hipEventDestroy(sl.ev_t0);
+  if (sl.ev_t1) (void)hipEventDestroy(sl.ev_t1);
+  if (sl.compute) (void)hipStreamDestroy(sl.compute);
+  if (sl.comm) (void)hipStreamDestroy(sl.comm);
+  sl = Slab();
+}
+
+bool validate_params(const lbm_params* p) {
+  return p && p->nx >= 1 && p->ny >= 2 && p->max_iters >= 0;
+}
+
+// Build one slab: allocate, upload mask rows, fill the lattice.
+int build_slab(lbm_ctx* c, int s, const int* obstacles, const float* cells_aos) {
+  Slab& sl = c->slab[s];
+  const lbm_params& p = c->p;
+  HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+  HIP_TRY(LBM_FAILURE, hipStreamCreateWithFlags(&sl.compute, hipStreamNonBlocking));
+  HIP_TRY(LBM_FAILURE, hipStreamCreateWithFlags(&sl.comm, hipStreamNonBlocking));
+  HIP_TRY(LBM_FAILURE, hipEventCreateWithFlags(&sl.ev_boundary, hipEventDisableTiming));
+  HIP_TRY(LBM_FAILURE, hipEventCreateWithFlags(&sl.ev_halo, hipEventDisableTiming));
+  HIP_TRY(LBM_FAILURE, hipEventCreate(&sl.ev_t0));
+  HIP_TRY(LBM_FAILURE, hipEventCreate(&sl.ev_t1));
+
+  const long cells = (long)sl.rows * c->pitch;
+  const long pad = env_int("LBM_PLANE_PAD_FLOATS", 0);
+  c->plane_stride[s] = round_up(cells, 64) + pad;
+  const size_t lat_bytes = (size_t)c->plane_stride[s] * lbm::kQ * sizeof(float);
+  for (int i = 0; i < 2; i++) HIP_TRY(LBM_FAILURE, hipMalloc(&sl.lat[i], lat_bytes));
+  HIP_TRY(LBM_FAILURE, hipMalloc(&sl.mask, (size_t)cells));
+  HIP_TRY(LBM_FAILURE, hipMalloc(&sl.partials, (size_t)kPartSlots * c->part_stride * sizeof(float)));
+  HIP_TRY(LBM_FAILURE, hipMemsetAsync(sl.partials, 0, (size_t)kPartSlots * c->part_stride * sizeof(float), sl.compute));
+  HIP_TRY(LBM_FAILURE, hipMalloc(&sl.tot_u, (size_t)(c->capacity > 0 ? c->capacity : 1) * sizeof(double)));
+  HIP_TRY(LBM_FAILURE, hipMemsetAsync(sl.tot_u, 0, (size_t)(c->capacity > 0 ? c->capacity : 1) * sizeof(double), sl.compute));
+  HIP_TRY(LBM_FAILURE, hipMalloc(&sl.scratch, 2 * kSumBlocks * sizeof(double)));
+  const size_t halo_bytes = 3 * (size_t)c->pitch * sizeof(float);
+  HIP_TRY(LBM_FAILURE, hipMalloc(&sl.send_south, halo_bytes));
+  HIP_TRY(LBM_FAILURE, hipMalloc(&sl.send_north, halo_bytes));
+  HIP_TRY(LBM_FAILURE, hipMalloc(&sl.recv_south, halo_bytes));
+  HIP_TRY(LBM_FAILURE, hipMalloc(&sl.recv_north, halo_bytes));
+
+  // obstacle mask: int (reference host type, SerialCode/d2q9-bgk.c:541) -> uint8 rows x pitch
+  {
+    std::vector<unsigned char> m((size_t)cells, 0);
+    for (int r = 0; r < sl.rows; r++) {
+      const int* src = obstacles + (size_t)(sl.row_first + r) * p.nx;
+      unsigned char* dst = m.data() + (size_t)r * c->pitch;
+      for (int x = 0; x < p.nx; x++) dst[x] = src[x] ? 1 : 0;
+    }
+    HIP_TRY(LBM_FAILURE, hipMemcpy(sl.mask, m.data(), (size_t)cells, hipMemcpyHostToDevice));
+  }
+
+  // lattice: zero both (pitch padding stays finite), then equilibrium or the caller's cells
+  for (int i = 0; i < 2; i++) HIP_TRY(LBM_FAILURE, hipMemsetAsync(sl.lat[i], 0, lat_bytes, sl.compute));
+  if (!cells_aos) {
+    const float r0 = p.density * 4.f / 9.f;  // SerialCode/d2q9-bgk.c:546-548
+    const float r1 = p.density / 9.f;
+    const float r2 = p.density / 36.f;
+    hipLaunchKernelGGL(lbm::init_equilibrium, dim3(ceil_div(cells, 256)), dim3(256), 0, sl.compute,
+                       sl.lat[0], c->plane_stride[s], cells, r0, r1, r2);
+    HIP_TRY(LBM_FAILURE, hipGetLastError());
+  } else {
+    // upload in chunks of rows through a staging buffer, transposing AoS -> SoA on the device
+    const int chunk_rows = (int)(((64L << 20) / ((long)p.nx * lbm::kQ * sizeof(float))) > 0
+                                     ? ((64L << 20) / ((long)p.nx * lbm::kQ * sizeof(float)))
+                                     : 1);
+    float* stage = nullptr;
+    HIP_TRY(LBM_FAILURE, hipMalloc(&stage, (size_t)chunk_rows * p.nx * lbm::kQ * sizeof(float)));
+    for (int r0 = 0; r0 < sl.rows; r0 += chunk_rows) {
+      const int nr = (sl.rows - r0 < chunk_rows) ? sl.rows - r0 : chunk_rows;
+      const size_t n = (size_t)nr * p.nx * lbm::kQ;
+      HIP_TRY(LBM_FAILURE, hipMemcpyAsync(stage, cells_aos + (size_t)(sl.row_first + r0) * p.nx * lbm::kQ,
+                                          n * sizeof(float), hipMemcpyHostToDevice, sl.compute));
+      hipLaunchKernelGGL(lbm::aos_to_soa, dim3(ceil_div((long)n, 256)), dim3(256), 0, sl.compute, stage,
+                         sl.lat[0], c->plane_stride[s], c->pitch, p.nx, r0, nr);
+      HIP_TRY(LBM_FAILURE, hipGetLastError());
+      HIP_TRY(LBM_FAILURE, hipStreamSynchronize(sl.compute));
+    }
+    HIP_TRY(LBM_FAILURE, hipFree(stage));
+  }
+  HIP_TRY(LBM_FAILURE, hipStreamSynchronize(sl.compute));
+  return LBM_SUCCESS;
+}
+
+int count_fluid(const lbm_params* p, const int* obstacles) {
+  long n = (long)p->nx * p->ny, fluid = 0;
+  for (long i = 0; i < n; i++) fluid += obstacles[i] ? 0 : 1;
+  return (int)fluid;
+}
+
+lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const float* cells_aos,
+                       int n_slabs, int math_mode, int rank, int world, const void* unique_id,
+                       int device) {
+  if (!validate_params(params)) LBM_FAIL(nullptr, "lbm_create: invalid parameters");
+  if (!obstacles) LBM_FAIL(nullptr, "lbm_create: obstacles is NULL");
+  if (math_mode != LBM_MATH_EXACT && math_mode != LBM_MATH_FAST)
+    LBM_FAIL(nullptr, "lbm_create: unknown math mode %d", math_mode);
+  if (n_slabs < 1 || n_slabs > kMaxSlabs) LBM_FAIL(nullptr, "lbm_create: n_gpus must be 1..%d", kMaxSlabs);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    LBM_FAIL(nullptr, "lbm_create: no HIP device available (this library has no CPU path)");
+
+  lbm_ctx* c = new lbm_ctx();
+  c->p = *params;
+  c->math_mode = math_mode;
+  c->rank = rank;
+  c->world = world;
+  c->capacity = params->max_iters;
+  c->fluid_cells = count_fluid(params, obstacles);
+  c->pitch = (int)round_up(params->nx, 64);
+  c->vec4 = (params->nx % 4 == 0);
+  c->n_slabs = n_slabs;
+
+  // rows of this context, then of each slab
+  if (lbm_partition_rows(params->ny, world, rank, &c->row_first, &c->row_count) != LBM_SUCCESS) {
+    delete c;
+    return nullptr;
+  }
+  const bool force_halo = env_int("LBM_FORCE_HALO", 0) != 0;
+  if (world > 1) c->halo = HALO_RCCL;
+  else if (n_slabs > 1 || force_halo) {
+    const char* h = getenv("LBM_HALO");
+    bool distinct = (n_slabs <= ndev);
+    c->halo = (h && !strcmp(h, "memcpy")) ? HALO_MEMCPY
+              : (h && !strcmp(h, "rccl")) ? HALO_RCCL
+              : (distinct ? HALO_RCCL : HALO_MEMCPY);
+  } else c->halo = HALO_SELF;
+
+  int max_blocks = 0;
+  for (int s = 0; s < n_slabs; s++) {
+    Slab& sl = c->slab[s];
+    int first = 0, count = c->row_count;
+    if (n_slabs > 1 && lbm_partition_rows(c->row_count, n_slabs, s, &first, &count) != LBM_SUCCESS) {
+      delete c;
+      return nullptr;
+    }
+    sl.device = (world > 1) ? device : (s % ndev);
+    sl.row_first = c->row_first + first;
+    sl.rows = count;
+    const int lid = params->ny - 2;  // SerialCode/d2q9-bgk.c:223
+    sl.accel_row = (lid >= sl.row_first && lid < sl.row_first + sl.rows) ? lid - sl.row_first : -1;
+    if (c->halo == HALO_SELF) {
+      sl.blocks_main = blocks_for_rows(c, sl.rows);
+      sl.blocks_boundary = 0;
+    } else {
+      if (sl.rows < 2) {
+        raise_error(__LINE__, "lbm_create: a slab needs at least 2 rows");
+        delete c;
+        return nullptr;
+      }
+      sl.blocks_main = blocks_for_rows(c, sl.rows - 2);
+      sl.blocks_boundary = blocks_for_rows(c, 2);
+    }
+    if (sl.blocks_main + sl.blocks_boundary > max_blocks) max_blocks = sl.blocks_main + sl.blocks_boundary;
+  }
+  c->part_stride = round_up(max_blocks, 64);
+
+  for (int s = 0; s < n_slabs; s++)
+    if (build_slab(c, s, obstacles, cells_aos) != LBM_SUCCESS) {
+      lbm_destroy(c);
+      return nullptr;
+    }
+
+  if (c->halo == HALO_RCCL) {
+    if (world > 1) {
+      ncclUniqueId id;
+      memcpy(&id, unique_id, sizeof(id));
+      if (hipSetDevice(c->slab[0].device) != hipSuccess ||
+          ncclCommInitRank(&c->slab[0].nccl, world, id, rank) != ncclSuccess) {
+        raise_error(__LINE__, "lbm_create_rank: ncclCommInitRank failed");
+        lbm_destroy(c);
+        return nullptr;
+      }
+    } else {
+      ncclComm_t comms[kMaxSlabs];
+      int devs[kMaxSlabs];
+      for (int s = 0; s < n_slabs; s++) devs[s] = c->slab[s].device;
+      if (ncclCommInitAll(comms, n_slabs, devs) != ncclSuccess) {
+        raise_error(__LINE__, "lbm_create: ncclCommInitAll failed (set LBM_HALO=memcpy when slabs share a device)");
+        lbm_destroy(c);
+        return nullptr;
+      }
+      for (int s = 0; s < n_slabs; s++) c->slab[s].nccl = comms[s];
+    }
+  }
+  return c;
+}
+
+// copy rows [0, rows) of slab s out through a staging buffer with `kernel` producing `per_cell`
+// floats per cell
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+void lbm_set_error_mode(int mode) { g_error_mode = (mode == LBM_ERRORS_RETURN) ? LBM_ERRORS_RETURN : LBM_ERRORS_DIE; }
+const char* lbm_last_error(void) { return g_last_error; }
+const char* lbm_version(void) { return "lbm_hip 0.1 gfx950"; }
+
+int lbm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int lbm_partition_rows(int ny, int parts, int index, int* first, int* count) {
+  if (parts < 1 || index < 0 || index >= parts || ny < 1)
+    LBM_FAIL(LBM_FAILURE, "lbm_partition_rows: bad arguments (ny=%d parts=%d index=%d)", ny, parts, index);
+  const int base = ny / parts, rem = ny % parts;
+  const int cnt = base + (index < rem ? 1 : 0);
+  const int fst = index * base + (index < rem ? index : rem);
+  if (parts > 1 && cnt < 2)
+    LBM_FAIL(LBM_FAILURE, "lbm_partition_rows: %d rows over %d parts leaves a part with fewer than 2 rows", ny, parts);
+  if (first) *first = fst;
+  if (count) *count = cnt;
+  return LBM_SUCCESS;
+}
+
+lbm_ctx* lbm_create(const lbm_params* params, const int* obstacles, const float* cells_aos,
+                    int n_gpus, int math_mode) {
+  return create_common(params, obstacles, cells_aos, n_gpus, math_mode, 0, 1, nullptr, 0);
+}
+
+int lbm_rccl_unique_id(void* id_out) {
+  if (!id_out) LBM_FAIL(LBM_FAILURE, "lbm_rccl_unique_id: NULL output");
+  static_assert(sizeof(ncclUniqueId) == LBM_RCCL_ID_BYTES, "RCCL unique id size");
+  ncclUniqueId id;
+  NCCL_TRY(LBM_FAILURE, ncclGetUniqueId(&id));
+  memcpy(id_out, &id, sizeof(id));
+  return LBM_SUCCESS;
+}
+
+lbm_ctx* lbm_create_rank(const lbm_params* params, const int* obstacles, const float* cells_aos,
+                         int rank, int world_size, const void* unique_id, int device, int math_mode) {
+  if (world_size < 1 || rank < 0 || rank >= world_size) LBM_FAIL(nullptr, "lbm_create_rank: bad rank %d of %d", rank, world_size);
+  if (world_size > 1 && !unique_id) LBM_FAIL(nullptr, "lbm_create_rank: unique_id is NULL");
+  return create_common(params, obstacles, cells_aos, 1, math_mode, rank, world_size, unique_id, device);
+}
+
+void lbm_destroy(lbm_ctx* c) {
+  if (!c) return;
+  for (int s = 0; s < c->n_slabs; s++) {
+    if (c->slab[s].compute) {
+      (void)hipSetDevice(c->slab[s].device);
+      (void)hipStreamSynchronize(c->slab[s].compute);
+      (void)hipStreamSynchronize(c->slab[s].comm);
+    }
+  }
+  for (int s = 0; s < c->n_slabs; s++) free_slab(c->slab[s]);
+  delete c;
+}
+
+int lbm_get_info(const lbm_ctx* c, lbm_info* out) {
+  if (!c || !out) LBM_FAIL(LBM_FAILURE, "lbm_get_info: NULL argument");
+  out->n_slabs = c->n_slabs;
+  out->row_first = c->row_first;
+  out->row_count = c->row_count;
+  out->fluid_cells = c->fluid_cells;
+  out->steps_done = c->steps_done;
+  out->math_mode = c->math_mode;
+  out->world_rank = c->rank;
+  out->world_size = c->world;
+  return LBM_SUCCESS;
+}
+
+int lbm_run(lbm_ctx* c, int n_steps) { return run_steps(c, n_steps, nullptr); }
+
+int lbm_run_timed(lbm_ctx* c, int n_steps, float* kernel_ms_per_step) {
+  if (!kernel_ms_per_step) LBM_FAIL(LBM_FAILURE, "lbm_run_timed: NULL output");
+  return run_steps(c, n_steps, kernel_ms_per_step);
+}
+
+int lbm_sync(lbm_ctx* c) {
+  if (!c) LBM_FAIL(LBM_FAILURE, "lbm_sync: null context");
+  for (int s = 0; s < c->n_slabs; s++) {
+    HIP_TRY(LBM_FAILURE, hipSetDevice(c->slab[s].device));
+    HIP_TRY(LBM_FAILURE, hipStreamSynchronize(c->slab[s].compute));
+    HIP_TRY(LBM_FAILURE, hipStreamSynchronize(c->slab[s].comm));
+  }
+  return LBM_SUCCESS;
+}
+
+int lbm_read_av_vels(lbm_ctx* c, float* out, int n) {
+  if (!c || !out) LBM_FAIL(LBM_FAILURE, "lbm_read_av_vels: NULL argument");
+  if (n < 0 || n > c->steps_done) LBM_FAIL(LBM_FAILURE, "lbm_read_av_vels: %d steps requested, %d recorded", n, c->steps_done);
+  if (n == 0) return LBM_SUCCESS;
+  if (lbm_sync(c) != LBM_SUCCESS) return LBM_FAILURE;
+  std::vector<double> total((size_t)n, 0.0), part((size_t)n);
+  for (int s = 0; s < c->n_slabs; s++) {
+    HIP_TRY(LBM_FAILURE, hipSetDevice(c->slab[s].device));
+    HIP_TRY(LBM_FAILURE, hipMemcpy(part.data(), c->slab[s].tot_u, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    for (int t = 0; t < n; t++) total[(size_t)t] += part[(size_t)t];
+  }
+  if (c->world > 1) {
+    // the reference's MPI_Reduce(av_vels, SUM) (MPI/d2q9-bgk.c:298-309), as an all-reduce
+    Slab& sl = c->slab[0];
+    double* tmp = nullptr;
+    HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+    HIP_TRY(LBM_FAILURE, hipMalloc(&tmp, (size_t)n * sizeof(double)));
+    HIP_TRY(LBM_FAILURE, hipMemcpy(tmp, total.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    NCCL_TRY(LBM_FAILURE, ncclAllReduce(tmp, tmp, (size_t)n, ncclDouble, ncclSum, sl.nccl, sl.comm));
+    HIP_TRY(LBM_FAILURE, hipStreamSynchronize(sl.comm));
+    HIP_TRY(LBM_FAILURE, hipMemcpy(total.data(), tmp, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(LBM_FAILURE, hipFree(tmp));
+  }
+  const float cells = (float)c->fluid_cells;
+  for (int t = 0; t < n; t++) out[t] = (float)total[(size_t)t] / cells;  // SerialCode/d2q9-bgk.c:457
+  return LBM_SUCCESS;
+}
+
+int lbm_read_cells(lbm_ctx* c, float* cells_aos) {
+  if (!c || !cells_aos) LBM_FAIL(LBM_FAILURE, "lbm_read_cells: NULL argument");
+  if (lbm_sync(c) != LBM_SUCCESS) return LBM_FAILURE;
+  const int nx = c->p.nx;
+  long chunk_rows = (64L << 20) / ((long)nx * lbm::kQ * sizeof(float));
+  if (chunk_rows < 1) chunk_rows = 1;
+  for (int s = 0; s < c->n_slabs; s++) {
+    Slab& sl = c->slab[s];
+    HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+    float* stage = nullptr;
+    HIP_TRY(LBM_FAILURE, hipMalloc(&stage, (size_t)chunk_rows * nx * lbm::kQ * sizeof(float)));
+    for (int r0 = 0; r0 < sl.rows; r0 += (int)chunk_rows) {
+      const int nr = (sl.rows - r0 < chunk_rows) ? sl.rows - r0 : (int)chunk_rows;
+      const size_t n = (size_t)nr * nx * lbm::kQ;
+      hipLaunchKernelGGL(lbm::soa_to_aos, dim3(ceil_div((long)n, 256)), dim3(256), 0, sl.compute,
+                         sl.lat[c->cur], stage, c->plane_stride[s], c->pitch, nx, r0, nr);
+      HIP_TRY(LBM_FAILURE, hipGetLastError());
+      HIP_TRY(LBM_FAILURE, hipMemcpyAsync(cells_aos + (size_t)(sl.row_first - c->row_first + r0) * nx * lbm::kQ, stage,
+                                          n * sizeof(float), hipMemcpyDeviceToHost, sl.compute));
+      HIP_TRY(LBM_FAILURE, hipStreamSynchronize(sl.compute));
+    }
+    HIP_TRY(LBM_FAILURE, hipFree(stage));
+  }
+  return LBM_SUCCESS;
+}
+
+int lbm_read_final_state(lbm_ctx* c, float* u_x, float* u_y, float* u_mag, float* pressure) {
+  if (!c || !u_x || !u_y || !u_mag || !pressure) LBM_FAIL(LBM_FAILURE, "lbm_read_final_state: NULL argument");
+  if (lbm_sync(c) != LBM_SUCCESS) return LBM_FAILURE;
+  const int nx = c->p.nx;
+  long chunk_rows = (16L << 20) / ((long)nx * sizeof(float));
+  if (chunk_rows < 1) chunk_rows = 1;
+  float* outs[4] = {u_x, u_y, u_mag, pressure};
+  for (int s = 0; s < c->n_slabs; s++) {
+    Slab& sl = c->slab[s];
+    HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+    float* stage = nullptr;
+    const size_t chunk_cells = (size_t)chunk_rows * nx;
+    HIP_TRY(LBM_FAILURE, hipMalloc(&stage, 4 * chunk_cells * sizeof(float)));
+    for (int r0 = 0; r0 < sl.rows; r0 += (int)chunk_rows) {
+      const int nr = (sl.rows - r0 < chunk_rows) ? sl.rows - r0 : (int)chunk_rows;
+      const size_t n = (size_t)nr * nx;
+      hipLaunchKernelGGL(lbm::final_state, dim3(ceil_div((long)n, 256)), dim3(256), 0, sl.compute,
+                         sl.lat[c->cur], sl.mask, c->plane_stride[s], c->pitch, nx, r0, nr, c->p.density,
+                         stage, stage + chunk_cells, stage + 2 * chunk_cells, stage + 3 * chunk_cells);
+      HIP_TRY(LBM_FAILURE, hipGetLastError());
+      const size_t off = (size_t)(sl.row_first - c->row_first + r0) * nx;
+      for (int k = 0; k < 4; k++)
+        HIP_TRY(LBM_FAILURE, hipMemcpyAsync(outs[k] + off, stage + k * chunk_cells, n * sizeof(float),
+                                            hipMemcpyDeviceToHost, sl.compute));
+      HIP_TRY(LBM_FAILURE, hipStreamSynchronize(sl.compute));
+    }
+    HIP_TRY(LBM_FAILURE, hipFree(stage));
+  }
+  return LBM_SUCCESS;
+}
+
+// global sums of |u| over fluid cells and of density over all cells
+static int lattice_totals(lbm_ctx* c, double* speed, double* mass) {
+  if (lbm_sync(c) != LBM_SUCCESS) return LBM_FAILURE;
+  double tot[2] = {0.0, 0.0};
+  std::vector<double> h(2 * kSumBlocks);
+  for (int s = 0; s < c->n_slabs; s++) {
+    Slab& sl = c->slab[s];
+    HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+    hipLaunchKernelGGL(lbm::lattice_sums, dim3(kSumBlocks), dim3(lbm::kBlock), 0, sl.compute, sl.lat[c->cur],
+                       sl.mask, c->plane_stride[s], c->pitch, c->p.nx, sl.rows, sl.scratch,
+                       sl.scratch + kSumBlocks);
+    HIP_TRY(LBM_FAILURE, hipGetLastError());
+    HIP_TRY(LBM_FAILURE, hipMemcpyAsync(h.data(), sl.scratch, 2 * kSumBlocks * sizeof(double),
+                                        hipMemcpyDeviceToHost, sl.compute));
+    HIP_TRY(LBM_FAILURE, hipStreamSynchronize(sl.compute));
+    for (int i = 0; i < kSumBlocks; i++) { tot[0] += h[i]; tot[1] += h[kSumBlocks + i]; }
+  }
+  if (c->world > 1) {
+    Slab& sl = c->slab[0];
+    HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+    HIP_TRY(LBM_FAILURE, hipMemcpy(sl.scratch, tot, 2 * sizeof(double), hipMemcpyHostToDevice));
+    NCCL_TRY(LBM_FAILURE, ncclAllReduce(sl.scratch, sl.scratch, 2, ncclDouble, ncclSum, sl.nccl, sl.comm));
+    HIP_TRY(LBM_FAILURE, hipStreamSynchronize(sl.comm));
+    HIP_TRY(LBM_FAILURE, hipMemcpy(tot, sl.scratch, 2 * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  *speed = tot[0];
+  *mass = tot[1];
+  return LBM_SUCCESS;
+}
+
+int lbm_av_velocity(lbm_ctx* c, float* out) {
+  if (!c || !out) LBM_FAIL(LBM_FAILURE, "lbm_av_velocity: NULL argument");
+  double speed, mass;
+  if (lattice_totals(c, &speed, &mass) != LBM_SUCCESS) return LBM_FAILURE;
+  *out = (float)speed / (float)c->fluid_cells;
+  return LBM_SUCCESS;
+}
+
+int lbm_total_density(lbm_ctx* c, double* out) {
+  if (!c || !out) LBM_FAIL(LBM_FAILURE, "lbm_total_density: NULL argument");
+  double speed, mass;
+  if (lattice_totals(c, &speed, &mass) != LBM_SUCCESS) return LBM_FAILURE;
+  *out = mass;
+  return LBM_SUCCESS;
+}
+
+int lbm_calc_reynolds(lbm_ctx* c, float* out) {
+  if (!c || !out) LBM_FAIL(LBM_FAILURE, "lbm_calc_reynolds: NULL argument");
+  float av;
+  if (lbm_av_velocity(c, &av) != LBM_SUCCESS) return LBM_FAILURE;
+  const float viscosity = 1.f / 6.f * (2.f / c->p.omega - 1.f);  // SerialCode/d2q9-bgk.c:639
+  *out = av * c->p.reynolds_dim / viscosity;                     // :641
+  return LBM_SUCCESS;
+}
+
+}  // extern "C"

@@ -1,0 +1,475 @@
+// lbm_kernels.hip.h -- CDNA4 (gfx950) device code of the D2Q9-BGK engine.
+//
+// One fused kernel per timestep replaces the reference's five sweeps
+// (accelerate_flow, propagate, rebound, collision, av_velocity;
+// /root/reference/SerialCode/d2q9-bgk.c:207-458):
+//   pull-stream 9 populations from the neighbours (periodic in x; in y either periodic or fed by
+//   packed halo rows), bounce back on blocked cells, BGK-relax fluid cells, sum |u| of the
+//   relaxed cells into one partial per workgroup, and apply NEXT step's accelerate_flow to the
+//   lid row before storing (so no separate pass over that row is needed).
+//
+// Layout: structure of arrays, 9 planes of fp32, plane k at base + k*plane_stride, row-major
+// rows x pitch.  Each value is read exactly once and written exactly once per step: the
+// algorithmic traffic is 72 B per lattice update, and there is no reuse to stage in LDS or to
+// feed MFMA -- this kernel is bound by HBM bandwidth.  Each lane owns 4 consecutive cells and
+// moves every plane with one 16-byte access; the +-1 column shifts of the six x-moving
+// populations are assembled from the lane's own aligned vector plus one neighbour dword.
+//
+// Speed numbering (SerialCode/d2q9-bgk.c:9-15):   6 2 5
+//                                                  3 0 1
+//                                                  7 4 8
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace lbm {
+
+constexpr int kBlock = 256;  // 4 waves of 64
+constexpr int kQ = 9;
+
+// 1/3 rounded to fp32, and the two constant divisors of the equilibrium, folded in fp32
+// exactly as the reference's "2.f * c_sq" and "2.f * c_sq * c_sq" (SerialCode/d2q9-bgk.c:308,367-370)
+constexpr float kCsq = 1.f / 3.f;
+constexpr float kTwoCsq = 2.f * kCsq;
+constexpr float kTwoCsqSq = 2.f * kCsq * kCsq;
+constexpr float kW0 = 4.f / 9.f;
+constexpr float kW1 = 1.f / 9.f;
+constexpr float kW2 = 1.f / 36.f;
+
+struct StepArgs {
+  const float* src;           // plane 0 of the source lattice
+  float* dst;                 // plane 0 of the destination lattice
+  const unsigned char* mask;  // rows x pitch, 1 = blocked
+  long plane_stride;          // floats between planes
+  int pitch;                  // floats between rows
+  int nx;                     // cells per row
+  int rows;                   // rows owned by this slab
+  int row_first;              // first slab row this launch advances
+  int row_stride;             // distance between the rows this launch advances (1 = contiguous)
+  int n_rows;                 // number of rows this launch advances
+  int accel_row;              // slab row that receives next step's acceleration, or -1
+  float omega;
+  float a1, a2;               // density*accel/9, density*accel/36 (SerialCode/d2q9-bgk.c:219-220)
+  float* partials;            // one fp32 partial sum of |u| per workgroup of this launch
+  // packed halo rows (NULL in the single-slab periodic case):
+  const float* recv_south;    // 3 x pitch: planes 2,5,6 of the row below slab row 0
+  const float* recv_north;    // 3 x pitch: planes 4,7,8 of the row above slab row rows-1
+  float* send_south;          // 3 x pitch: planes 4,7,8 of slab row 0 after this step
+  float* send_north;          // 3 x pitch: planes 2,5,6 of slab row rows-1 after this step
+};
+
+// ---------------------------------------------------------------------------------------------
+// per-cell arithmetic
+// ---------------------------------------------------------------------------------------------
+
+// EXACT: the reference's expression trees, IEEE division and sqrt, no contraction
+// (the library is compiled with -ffp-contract=off).  SerialCode/d2q9-bgk.c:325-401, 426-450.
+__device__ __forceinline__ void moments_exact(const float (&f)[kQ], float& rho, float& ux, float& uy) {
+  float d = f[0];
+#pragma unroll
+  for (int k = 1; k < kQ; k++) d += f[k];
+  rho = d;
+  ux = (f[1] + f[5] + f[8] - (f[3] + f[6] + f[7])) / d;
+  uy = (f[2] + f[5] + f[6] - (f[4] + f[7] + f[8])) / d;
+}
+
+__device__ __forceinline__ float equilibrium_exact(float w_rho, float u, float usq_term) {
+  return w_rho * (1.f + u / kCsq + (u * u) / kTwoCsqSq - usq_term);
+}
+
+template <bool EXACT>
+__device__ __forceinline__ void collide(const float (&t)[kQ], float omega, float (&r)[kQ], float& speed);
+
+template <>
+__device__ __forceinline__ void collide<true>(const float (&t)[kQ], float omega, float (&r)[kQ],
+                                              float& speed) {
+  float rho, ux, uy;
+  moments_exact(t, rho, ux, uy);
+  const float u_sq = ux * ux + uy * uy;
+  const float usq_term = u_sq / kTwoCsq;
+  const float w1r = kW1 * rho, w2r = kW2 * rho;
+  float eq[kQ];
+  eq[0] = kW0 * rho * (1.f - usq_term);
+  eq[1] = equilibrium_exact(w1r, ux, usq_term);
+  eq[2] = equilibrium_exact(w1r, uy, usq_term);
+  eq[3] = equilibrium_exact(w1r, -ux, usq_term);
+  eq[4] = equilibrium_exact(w1r, -uy, usq_term);
+  eq[5] = equilibrium_exact(w2r, ux + uy, usq_term);
+  eq[6] = equilibrium_exact(w2r, -ux + uy, usq_term);
+  eq[7] = equilibrium_exact(w2r, -ux - uy, usq_term);
+  eq[8] = equilibrium_exact(w2r, ux - uy, usq_term);
+#pragma unroll
+  for (int k = 0; k < kQ; k++) r[k] = t[k] + omega * (eq[k] - t[k]);
+  // av_velocity() looks at the relaxed populations (SerialCode/d2q9-bgk.c:169, 426-450)
+  float rho2, ux2, uy2;
+  moments_exact(r, rho2, ux2, uy2);
+  speed = __fsqrt_rn((ux2 * ux2) + (uy2 * uy2));
+}
+
+// FAST: one reciprocal, multiplies by 3, 4.5, 1.5 and explicit FMAs.  BGK conserves density and
+// momentum, so |u| of the relaxed cell is taken from the pre-collision moments.
+template <>
+__device__ __forceinline__ void collide<false>(const float (&t)[kQ], float omega, float (&r)[kQ],
+                                               float& speed) {
+  const float rho = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7])) + t[8];
+  const float inv = 1.f / rho;
+  const float ux = ((t[1] + t[5] + t[8]) - (t[3] + t[6] + t[7])) * inv;
+  const float uy = ((t[2] + t[5] + t[6]) - (t[4] + t[7] + t[8])) * inv;
+  const float u_sq = __fmaf_rn(ux, ux, uy * uy);
+  const float base = __fmaf_rn(-1.5f, u_sq, 1.f);
+  const float w0r = omega * kW0 * rho, w1r = omega * kW1 * rho, w2r = omega * kW2 * rho;
+  const float keep = 1.f - omega;
+  auto relax = [&](float tk, float wr, float u) {
+    const float poly = __fmaf_rn(u, __fmaf_rn(4.5f, u, 3.f), base);
+    return __fmaf_rn(wr, poly, keep * tk);
+  };
+  r[0] = __fmaf_rn(w0r, base, keep * t[0]);
+  r[1] = relax(t[1], w1r, ux);
+  r[2] = relax(t[2], w1r, uy);
+  r[3] = relax(t[3], w1r, -ux);
+  r[4] = relax(t[4], w1r, -uy);
+  r[5] = relax(t[5], w2r, ux + uy);
+  r[6] = relax(t[6], w2r, uy - ux);
+  r[7] = relax(t[7], w2r, -ux - uy);
+  r[8] = relax(t[8], w2r, ux - uy);
+  speed = __fsqrt_rn(u_sq);
+}
+
+// accelerate_flow() on one cell (SerialCode/d2q9-bgk.c:229-242)
+__device__ __forceinline__ void accelerate(float (&f)[kQ], float a1, float a2) {
+  if ((f[3] - a1) > 0.f && (f[6] - a2) > 0.f && (f[7] - a2) > 0.f) {
+    f[1] += a1;  f[5] += a2;  f[8] += a2;
+    f[3] -= a1;  f[6] -= a2;  f[7] -= a2;
+  }
+}
+
+// rebound(): mirrored copy, speed 0 kept (SerialCode/d2q9-bgk.c:291-298)
+__device__ __forceinline__ void bounce(const float (&t)[kQ], float (&r)[kQ]) {
+  r[0] = t[0];
+  r[1] = t[3];  r[2] = t[4];  r[3] = t[1];  r[4] = t[2];
+  r[5] = t[7];  r[6] = t[8];  r[7] = t[5];  r[8] = t[6];
+}
+
+// ---------------------------------------------------------------------------------------------
+// workgroup reduction: wave64 shuffles, then one LDS hop across the 4 waves
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ float block_sum(float v) {
+  __shared__ float wave_part[kBlock / 64];
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_part[wave] = v;
+  __syncthreads();
+  float total = 0.f;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; w++) total += wave_part[w];
+  }
+  return total;  // valid in thread 0
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused step, 4 cells per lane (nx % 4 == 0, pitch % 4 == 0)
+// ---------------------------------------------------------------------------------------------
+template <bool EXACT>
+__global__ __launch_bounds__(kBlock) void step_vec4(const StepArgs a) {
+  const int quads_x = a.nx >> 2;
+  const long q = (long)blockIdx.x * kBlock + threadIdx.x;
+  const long n_quads = (long)quads_x * a.n_rows;
+  float my_sum = 0.f;
+
+  if (q < n_quads) {
+    const int rsel = (int)(q / quads_x);
+    const int x0 = (int)(q - (long)rsel * quads_x) << 2;
+    const int row = a.row_first + rsel * a.row_stride;
+
+    // neighbour columns with periodic wrap (SerialCode/d2q9-bgk.c:258,260)
+    const int xw = (x0 == 0) ? a.nx - 1 : x0 - 1;
+    const int xe = (x0 + 4 == a.nx) ? 0 : x0 + 4;
+
+    const long ps = a.plane_stride;
+    const float* c_row = a.src + (long)row * a.pitch;  // plane 0, this row
+    // row below (speeds 2,5,6 arrive from it) and above (4,7,8), :257,259
+    const float *s2, *s5, *s6, *n4, *n7, *n8;
+    if (row == 0 && a.recv_south) {
+      s2 = a.recv_south;  s5 = s2 + a.pitch;  s6 = s5 + a.pitch;
+    } else {
+      const int rs = (row == 0) ? a.rows - 1 : row - 1;
+      const float* b = a.src + (long)rs * a.pitch;
+      s2 = b + 2 * ps;  s5 = b + 5 * ps;  s6 = b + 6 * ps;
+    }
+    if (row == a.rows - 1 && a.recv_north) {
+      n4 = a.recv_north;  n7 = n4 + a.pitch;  n8 = n7 + a.pitch;
+    } else {
+      const int rn = (row == a.rows - 1) ? 0 : row + 1;
+      const float* b = a.src + (long)rn * a.pitch;
+      n4 = b + 4 * ps;  n7 = b + 7 * ps;  n8 = b + 8 * ps;
+    }
+
+    // 9 aligned 16-byte loads + 6 neighbour dwords
+    const float4 v0 = *reinterpret_cast<const float4*>(c_row + x0);
+    const float4 v1 = *reinterpret_cast<const float4*>(c_row + 1 * ps + x0);
+    const float4 v3 = *reinterpret_cast<const float4*>(c_row + 3 * ps + x0);
+    const float4 v2 = *reinterpret_cast<const float4*>(s2 + x0);
+    const float4 v5 = *reinterpret_cast<const float4*>(s5 + x0);
+    const float4 v6 = *reinterpret_cast<const float4*>(s6 + x0);
+    const float4 v4 = *reinterpret_cast<const float4*>(n4 + x0);
+    const float4 v7 = *reinterpret_cast<const float4*>(n7 + x0);
+    const float4 v8 = *reinterpret_cast<const float4*>(n8 + x0);
+    const float e1 = c_row[1 * ps + xw];  // speed 1 travels east: comes from the west cell
+    const float e3 = c_row[3 * ps + xe];
+    const float e5 = s5[xw];
+    const float e6 = s6[xe];
+    const float e7 = n7[xe];
+    const float e8 = n8[xw];
+    const uchar4 m = *reinterpret_cast<const uchar4*>(a.mask + (long)row * a.pitch + x0);
+
+    // streamed populations of the 4 cells: t[j][k]
+    float t[4][kQ] = {
+        {v0.x, e1,   v2.x, v3.y, v4.x, e5,   v6.y, v7.y, e8},
+        {v0.y, v1.x, v2.y, v3.z, v4.y, v5.x, v6.z, v7.z, v8.x},
+        {v0.z, v1.y, v2.z, v3.w, v4.z, v5.y, v6.w, v7.w, v8.y},
+        {v0.w, v1.z, v2.w, e3,   v4.w, v5.z, e6,   e7,   v8.z}};
+    const unsigned char blocked[4] = {m.x, m.y, m.z, m.w};
+    const bool lid = (row == a.accel_row);
+
+    float r[4][kQ];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (blocked[j]) {
+        bounce(t[j], r[j]);
+      } else {
+        float speed;
+        collide<EXACT>(t[j], a.omega, r[j], speed);
+        my_sum += speed;
+        if (lid) accelerate(r[j], a.a1, a.a2);
+      }
+    }
+
+    float* d_row = a.dst + (long)row * a.pitch + x0;
+#pragma unroll
+    for (int k = 0; k < kQ; k++)
+      *reinterpret_cast<float4*>(d_row + k * ps) = make_float4(r[0][k], r[1][k], r[2][k], r[3][k]);
+
+    // packed halo rows for the neighbours' next step
+    if (a.send_south && row == 0) {
+      float* o = a.send_south + x0;
+      *reinterpret_cast<float4*>(o) = make_float4(r[0][4], r[1][4], r[2][4], r[3][4]);
+      *reinterpret_cast<float4*>(o + a.pitch) = make_float4(r[0][7], r[1][7], r[2][7], r[3][7]);
+      *reinterpret_cast<float4*>(o + 2 * a.pitch) = make_float4(r[0][8], r[1][8], r[2][8], r[3][8]);
+    }
+    if (a.send_north && row == a.rows - 1) {
+      float* o = a.send_north + x0;
+      *reinterpret_cast<float4*>(o) = make_float4(r[0][2], r[1][2], r[2][2], r[3][2]);
+      *reinterpret_cast<float4*>(o + a.pitch) = make_float4(r[0][5], r[1][5], r[2][5], r[3][5]);
+      *reinterpret_cast<float4*>(o + 2 * a.pitch) = make_float4(r[0][6], r[1][6], r[2][6], r[3][6]);
+    }
+  }
+
+  const float total = block_sum(my_sum);
+  if (threadIdx.x == 0) a.partials[blockIdx.x] = total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused step, 1 cell per lane: any nx (fallback for widths that are not a multiple of 4)
+// ---------------------------------------------------------------------------------------------
+template <bool EXACT>
+__global__ __launch_bounds__(kBlock) void step_scalar(const StepArgs a) {
+  const long q = (long)blockIdx.x * kBlock + threadIdx.x;
+  const long n_cells = (long)a.nx * a.n_rows;
+  float my_sum = 0.f;
+  if (q < n_cells) {
+    const int rsel = (int)(q / a.nx);
+    const int x = (int)(q - (long)rsel * a.nx);
+    const int row = a.row_first + rsel * a.row_stride;
+    const int xw = (x == 0) ? a.nx - 1 : x - 1;
+    const int xe = (x + 1 == a.nx) ? 0 : x + 1;
+    const long ps = a.plane_stride;
+    const float* c_row = a.src + (long)row * a.pitch;
+    const float *s2, *s5, *s6, *n4, *n7, *n8;
+    if (row == 0 && a.recv_south) {
+      s2 = a.recv_south;  s5 = s2 + a.pitch;  s6 = s5 + a.pitch;
+    } else {
+      const int rs = (row == 0) ? a.rows - 1 : row - 1;
+      const float* b = a.src + (long)rs * a.pitch;
+      s2 = b + 2 * ps;  s5 = b + 5 * ps;  s6 = b + 6 * ps;
+    }
+    if (row == a.rows - 1 && a.recv_north) {
+      n4 = a.recv_north;  n7 = n4 + a.pitch;  n8 = n7 + a.pitch;
+    } else {
+      const int rn = (row == a.rows - 1) ? 0 : row + 1;
+      const float* b = a.src + (long)rn * a.pitch;
+      n4 = b + 4 * ps;  n7 = b + 7 * ps;  n8 = b + 8 * ps;
+    }
+    float t[kQ] = {c_row[x], c_row[1 * ps + xw], s2[x], c_row[3 * ps + xe], n4[x],
+                   s5[xw],   s6[xe],             n7[xe], n8[xw]};
+    float r[kQ];
+    if (a.mask[(long)row * a.pitch + x]) {
+      bounce(t, r);
+    } else {
+      float speed;
+      collide<EXACT>(t, a.omega, r, speed);
+      my_sum = speed;
+      if (row == a.accel_row) accelerate(r, a.a1, a.a2);
+    }
+    float* d = a.dst + (long)row * a.pitch + x;
+#pragma unroll
+    for (int k = 0; k < kQ; k++) d[k * ps] = r[k];
+    if (a.send_south && row == 0) {
+      a.send_south[x] = r[4];  a.send_south[a.pitch + x] = r[7];  a.send_south[2 * a.pitch + x] = r[8];
+    }
+    if (a.send_north && row == a.rows - 1) {
+      a.send_north[x] = r[2];  a.send_north[a.pitch + x] = r[5];  a.send_north[2 * a.pitch + x] = r[6];
+    }
+  }
+  const float total = block_sum(my_sum);
+  if (threadIdx.x == 0) a.partials[blockIdx.x] = total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small kernels around the step
+// ---------------------------------------------------------------------------------------------
+
+// accelerate_flow() as its own pass (SerialCode/d2q9-bgk.c:216-246): used once before the first
+// step of a run; later steps get it from the epilogue of the step kernel.
+__global__ void accelerate_row(float* lat, const unsigned char* mask, long ps, int pitch, int nx,
+                               int row, float a1, float a2) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= nx) return;
+  const long c = (long)row * pitch + x;
+  if (mask[c]) return;
+  float f[kQ];
+#pragma unroll
+  for (int k = 0; k < kQ; k++) f[k] = lat[k * ps + c];
+  accelerate(f, a1, a2);
+  lat[1 * ps + c] = f[1];  lat[3 * ps + c] = f[3];  lat[5 * ps + c] = f[5];
+  lat[6 * ps + c] = f[6];  lat[7 * ps + c] = f[7];  lat[8 * ps + c] = f[8];
+}
+
+// fill the packed send rows from the current lattice (before the first halo exchange of a run)
+__global__ void pack_halo(const float* lat, long ps, int pitch, int nx, int rows,
+                          float* send_south, float* send_north) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= nx) return;
+  const long top = (long)(rows - 1) * pitch + x;
+  send_south[x] = lat[4 * ps + x];
+  send_south[pitch + x] = lat[7 * ps + x];
+  send_south[2 * pitch + x] = lat[8 * ps + x];
+  send_north[x] = lat[2 * ps + top];
+  send_north[pitch + x] = lat[5 * ps + top];
+  send_north[2 * pitch + x] = lat[6 * ps + top];
+}
+
+// sum the per-workgroup partials of up to gridDim.x steps: block s adds partials[s][0..n_part)
+// in a fixed order (double accumulation) -> tot_u[step_base + s].  Deterministic, no atomics.
+__global__ __launch_bounds__(kBlock) void reduce_partials(const float* partials, int n_part,
+                                                          long slot_stride, double* tot_u,
+                                                          int step_base) {
+  __shared__ double sh[kBlock];
+  const float* p = partials + (long)blockIdx.x * slot_stride;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n_part; i += kBlock) acc += (double)p[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = kBlock / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) tot_u[step_base + blockIdx.x] = sh[0];
+}
+
+// uniform equilibrium start (SerialCode/d2q9-bgk.c:546-567)
+__global__ void init_equilibrium(float* lat, long ps, long n, float r0, float r1, float r2) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  lat[i] = r0;
+  lat[1 * ps + i] = r1;  lat[2 * ps + i] = r1;  lat[3 * ps + i] = r1;  lat[4 * ps + i] = r1;
+  lat[5 * ps + i] = r2;  lat[6 * ps + i] = r2;  lat[7 * ps + i] = r2;  lat[8 * ps + i] = r2;
+}
+
+// AoS (reference host layout, 9 floats per cell) <-> SoA planes, rows [row0, row0+nrows)
+__global__ void aos_to_soa(const float* aos, float* lat, long ps, int pitch, int nx, int row0,
+                           int nrows) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = (long)nx * nrows * kQ;
+  if (i >= n) return;
+  const long cell = i / kQ;
+  const int k = (int)(i - cell * kQ);
+  const int r = (int)(cell / nx), x = (int)(cell - (long)r * nx);
+  lat[k * ps + (long)(row0 + r) * pitch + x] = aos[i];
+}
+
+__global__ void soa_to_aos(const float* lat, float* aos, long ps, int pitch, int nx, int row0,
+                           int nrows) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = (long)nx * nrows * kQ;
+  if (i >= n) return;
+  const long cell = i / kQ;
+  const int k = (int)(i - cell * kQ);
+  const int r = (int)(cell / nx), x = (int)(cell - (long)r * nx);
+  aos[i] = lat[k * ps + (long)(row0 + r) * pitch + x];
+}
+
+// write_values() quantities (SerialCode/d2q9-bgk.c:684-719), always in the exact arithmetic
+__global__ void final_state(const float* lat, const unsigned char* mask, long ps, int pitch, int nx,
+                            int row0, int nrows, float density, float* ux_o, float* uy_o,
+                            float* um_o, float* pr_o) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = (long)nx * nrows;
+  if (i >= n) return;
+  const int r = (int)(i / nx), x = (int)(i - (long)r * nx);
+  const long c = (long)(row0 + r) * pitch + x;
+  if (mask[c]) {
+    ux_o[i] = 0.f;  uy_o[i] = 0.f;  um_o[i] = 0.f;
+    pr_o[i] = density * kCsq;
+  } else {
+    float f[kQ];
+#pragma unroll
+    for (int k = 0; k < kQ; k++) f[k] = lat[k * ps + c];
+    float rho, ux, uy;
+    moments_exact(f, rho, ux, uy);
+    ux_o[i] = ux;  uy_o[i] = uy;
+    um_o[i] = __fsqrt_rn((ux * ux) + (uy * uy));
+    pr_o[i] = rho * kCsq;
+  }
+}
+
+// av_velocity() of a stored lattice (SerialCode/d2q9-bgk.c:409-458): per-workgroup partials of
+// sum |u| in double; reduced by reduce_doubles.  Also serves total_density() (:644-660).
+__global__ __launch_bounds__(kBlock) void lattice_sums(const float* lat, const unsigned char* mask,
+                                                       long ps, int pitch, int nx, int rows,
+                                                       double* speed_part, double* mass_part) {
+  __shared__ double sh_s[kBlock], sh_m[kBlock];
+  double s = 0.0, m = 0.0;
+  const long n = (long)nx * rows;
+  for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) {
+    const int r = (int)(i / nx), x = (int)(i - (long)r * nx);
+    const long c = (long)r * pitch + x;
+    float f[kQ];
+#pragma unroll
+    for (int k = 0; k < kQ; k++) f[k] = lat[k * ps + c];
+    float rho, ux, uy;
+    moments_exact(f, rho, ux, uy);
+    m += (double)rho;
+    if (!mask[c]) s += (double)__fsqrt_rn((ux * ux) + (uy * uy));
+  }
+  sh_s[threadIdx.x] = s;  sh_m[threadIdx.x] = m;
+  __syncthreads();
+  for (int k = kBlock / 2; k > 0; k >>= 1) {
+    if (threadIdx.x < k) {
+      sh_s[threadIdx.x] += sh_s[threadIdx.x + k];
+      sh_m[threadIdx.x] += sh_m[threadIdx.x + k];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    speed_part[blockIdx.x] = sh_s[0];
+    mass_part[blockIdx.x] = sh_m[0];
+  }
+}
+
+}  // namespace lbm
