@@ -102,7 +102,7 @@ __device__ __forceinline__ void collide<true>(const float (&t)[kQ], float omega,
   // av_velocity() looks at the relaxed populations (SerialCode/d2q9-bgk.c:169, 426-450)
   float rho2, ux2, uy2;
   moments_exact(r, rho2, ux2, uy2);
-  speed = __fsqrt_rn((ux2 * ux2) + (uy2 * uy2));
+  speed = sqrtf((ux2 * ux2) + (uy2 * uy2));  // IEEE: __fsqrt_rn is the native approximation
 }
 
 // FAST: one reciprocal, multiplies by 3, 4.5, 1.5 and explicit FMAs.  BGK conserves density and
@@ -131,7 +131,7 @@ __device__ __forceinline__ void collide<false>(const float (&t)[kQ], float omega
   r[6] = relax(t[6], w2r, uy - ux);
   r[7] = relax(t[7], w2r, -ux - uy);
   r[8] = relax(t[8], w2r, ux - uy);
-  speed = __fsqrt_rn(u_sq);
+  speed = __builtin_amdgcn_sqrtf(u_sq);  // v_sqrt_f32, 1 ulp
 }
 
 // accelerate_flow() on one cell (SerialCode/d2q9-bgk.c:229-242)
@@ -433,7 +433,7 @@ __global__ void final_state(const float* lat, const unsigned char* mask, long ps
     float rho, ux, uy;
     moments_exact(f, rho, ux, uy);
     ux_o[i] = ux;  uy_o[i] = uy;
-    um_o[i] = __fsqrt_rn((ux * ux) + (uy * uy));
+    um_o[i] = sqrtf((ux * ux) + (uy * uy));
     pr_o[i] = rho * kCsq;
   }
 }
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(kBlock) void lattice_sums(const float* lat, const u
     float rho, ux, uy;
     moments_exact(f, rho, ux, uy);
     m += (double)rho;
-    if (!mask[c]) s += (double)__fsqrt_rn((ux * ux) + (uy * uy));
+    if (!mask[c]) s += (double)sqrtf((ux * ux) + (uy * uy));
   }
   sh_s[threadIdx.x] = s;  sh_m[threadIdx.x] = m;
   __syncthreads();

@@ -1,10 +1,12 @@
 """GPU parity: the HIP engine (through the C ABI) against the CPU oracle on the same inputs.
 
-Bar: EXACT mode is BIT-IDENTICAL to the oracle's lattice (and therefore to the reference's
-SerialCode binary, which the oracle is pinned to).  av_vels differ only by summation order
-(the reference sums left to right in fp32, the GPU sums per workgroup then in double), bounded
-here at 1e-5 relative -- the reference's own OpenMP variant moves them by 5e-5
-(SURVEY.md section 8c).  FAST mode (reciprocal multiplies + FMA) is held to the north-star
+Bar: EXACT mode is BIT-IDENTICAL to the oracle's lattice and per-cell outputs (and therefore to
+the reference's SerialCode binary, which the oracle is pinned to).  av_vels differ only by
+summation order: the reference adds 10^4..10^8 fp32 terms left to right (rounding noise of order
+sqrt(n)*2^-24, 4e-5 observed on 128x256; its own OpenMP variant moves them by 5e-5, SURVEY.md
+section 8c), the GPU adds 1024-cell fp32 partials in double.  So av_vels are compared (a) with the
+oracle's sequential fp32 value at 2e-4 relative and (b) with a float64 re-summation of the
+oracle's per-cell |u| at 1e-6 relative (test_av_vels_against_float64_resummation).  FAST mode (reciprocal multiplies + FMA) is held to the north-star
 tolerance, the check.py rule: max |100*(ref-sim)/sim| <= 1 % on av_vels and on pressure
 (/root/reference/check/check.py:83-99,136-148).
 """
@@ -15,7 +17,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-AV_RTOL = 1e-5          # summation-order bound for av_vels in exact mode
+AV_RTOL = 2e-4          # vs the reference's sequential fp32 sum (see module docstring)
 CHECK_TOL_PCT = 1.0     # check.py default tolerance (check/check.py:19-24)
 
 
@@ -74,6 +76,22 @@ def test_exact_bitwise_ragged_widths(lbm, oracle, nx, ny):
     ref_cells, ref_av, got_cells, got_av, _ = run_both(lbm, oracle, p, ob, cells, 12)
     assert np.array_equal(ref_cells.view(np.uint32), got_cells.view(np.uint32))
     np.testing.assert_allclose(got_av, ref_av, rtol=AV_RTOL, atol=1e-12)
+
+
+def test_av_vels_against_float64_resummation(lbm, oracle, datasets):
+    """Tight av_vels check: per-cell |u| is bit-identical, so only the summation differs."""
+    p, ob = datasets("128x256")
+    ref = oracle.init_cells(p)
+    steps = 40
+    want = []
+    for _ in range(steps):
+        oracle.run(p, ref, ob, 1)
+        u = oracle.final_state(p, ref, ob)["u"]
+        want.append(np.float32(np.float32(u[ob == 0].astype(np.float64).sum()) / np.float32((ob == 0).sum())))
+    with lbm.Engine(p, ob, oracle.init_cells(p)) as eng:
+        eng.run(steps)
+        got = eng.av_vels(steps)
+    np.testing.assert_allclose(got, np.array(want, dtype=np.float32), rtol=1e-6, atol=0)
 
 
 def test_all_blocked_and_no_blocked(lbm, oracle):
@@ -160,8 +178,10 @@ def test_diagnostics_match_oracle(lbm, oracle, datasets):
         eng.run(500)
         assert eng.av_velocity() == pytest.approx(oracle.av_velocity(p, ref_cells, ob), rel=AV_RTOL)
         assert eng.reynolds() == pytest.approx(oracle.calc_reynolds(p, ref_cells, ob), rel=AV_RTOL)
-        # fp32 sequential sum in the oracle vs double on the device
-        assert eng.total_density() == pytest.approx(oracle.total_density(p, ref_cells), rel=1e-4)
+        # the device sums in double: compare with a float64 sum of the (bit-identical) lattice;
+        # the oracle's sequential fp32 sum (total_density(), :644-660) carries ~1e-4 of rounding
+        assert eng.total_density() == pytest.approx(float(ref_cells.astype(np.float64).sum()), rel=1e-9)
+        assert eng.total_density() == pytest.approx(oracle.total_density(p, ref_cells), rel=1e-3)
         # mass conservation (the reference's DEBUG invariant, :175-179)
         assert eng.total_density() == pytest.approx(mass0, rel=1e-5)
 
