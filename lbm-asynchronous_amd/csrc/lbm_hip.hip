@@ -94,7 +94,8 @@ constexpr int kSumBlocks = 1024;
 struct lbm_ctx {
   lbm_params p;
   int pitch = 0;
-  long plane_stride[kMaxSlabs] = {0};
+  long plane_stride = 0;  // floats between the 9 planes of one row (= pitch + optional pad)
+  long row_pitch = 0;     // floats between lattice rows (= 9 * plane_stride)
   int n_slabs = 0;
   Slab slab[kMaxSlabs];
   int cur = 0;  // lattice holding the current state
@@ -108,6 +109,8 @@ struct lbm_ctx {
   int slot_fill = 0;  // partial slots used since the last reduce
   long part_stride = 0;
   bool vec4 = false;
+  int neigh = 0;  // step_vec4 NEIGH flavour (LBM_NEIGH overrides)
+  int nts = 1;    // nontemporal stores (LBM_NTS overrides)
 };
 
 namespace {
@@ -121,8 +124,9 @@ int launch_step(lbm_ctx* c, int s, int row_first, int row_stride, int n_rows, in
   a.src = sl.lat[c->cur];
   a.dst = sl.lat[c->cur ^ 1];
   a.mask = sl.mask;
-  a.plane_stride = c->plane_stride[s];
+  a.plane_stride = c->plane_stride;
   a.pitch = c->pitch;
+  a.row_pitch = c->row_pitch;
   a.nx = c->p.nx;
   a.rows = sl.rows;
   a.row_first = row_first;
@@ -142,8 +146,16 @@ int launch_step(lbm_ctx* c, int s, int row_first, int row_stride, int n_rows, in
   const bool exact = (c->math_mode == LBM_MATH_EXACT);
   if (c->vec4) {
     const int blocks = ceil_div((long)(c->p.nx / 4) * n_rows, lbm::kBlock);
-    if (exact) hipLaunchKernelGGL(lbm::step_vec4<true>, dim3(blocks), dim3(lbm::kBlock), 0, sl.compute, a);
-    else       hipLaunchKernelGGL(lbm::step_vec4<false>, dim3(blocks), dim3(lbm::kBlock), 0, sl.compute, a);
+    // kernel flavour: [math][neighbour exchange][nontemporal stores]; tuned defaults, see DESIGN.md
+    typedef void (*step_fn)(const lbm::StepArgs);
+    static const step_fn table[2][3][2] = {
+        {{lbm::step_vec4<0, 0, false>, lbm::step_vec4<0, 0, true>},
+         {lbm::step_vec4<0, 1, false>, lbm::step_vec4<0, 1, true>},
+         {lbm::step_vec4<0, 2, false>, lbm::step_vec4<0, 2, true>}},
+        {{lbm::step_vec4<1, 0, false>, lbm::step_vec4<1, 0, true>},
+         {lbm::step_vec4<1, 1, false>, lbm::step_vec4<1, 1, true>},
+         {lbm::step_vec4<1, 2, false>, lbm::step_vec4<1, 2, true>}}};
+    hipLaunchKernelGGL(table[exact ? 0 : 1][c->neigh][c->nts], dim3(blocks), dim3(lbm::kBlock), 0, sl.compute, a);
   } else {
     const int blocks = ceil_div((long)c->p.nx * n_rows, lbm::kBlock);
     if (exact) hipLaunchKernelGGL(lbm::step_scalar<true>, dim3(blocks), dim3(lbm::kBlock), 0, sl.compute, a);
@@ -255,13 +267,13 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
     HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
     if (sl.accel_row >= 0) {
       hipLaunchKernelGGL(lbm::accelerate_row, dim3(ceil_div(c->p.nx, 256)), dim3(256), 0, sl.compute,
-                         sl.lat[c->cur], sl.mask, c->plane_stride[s], c->pitch, c->p.nx, sl.accel_row,
+                         sl.lat[c->cur], sl.mask, c->plane_stride, c->row_pitch, c->pitch, c->p.nx, sl.accel_row,
                          a1, a2);
       HIP_TRY(LBM_FAILURE, hipGetLastError());
     }
     if (halo) {
       hipLaunchKernelGGL(lbm::pack_halo, dim3(ceil_div(c->p.nx, 256)), dim3(256), 0, sl.compute,
-                         sl.lat[c->cur], c->plane_stride[s], c->pitch, c->p.nx, sl.rows, sl.send_south,
+                         sl.lat[c->cur], c->plane_stride, c->row_pitch, c->pitch, c->p.nx, sl.rows, sl.send_south,
                          sl.send_north);
       HIP_TRY(LBM_FAILURE, hipGetLastError());
       HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_boundary, sl.compute));
@@ -367,10 +379,8 @@ int build_slab(lbm_ctx* c, int s, const int* obstacles, const float* cells_aos) 
   HIP_TRY(LBM_FAILURE, hipEventCreate(&sl.ev_t0));
   HIP_TRY(LBM_FAILURE, hipEventCreate(&sl.ev_t1));
 
-  const long cells = (long)sl.rows * c->pitch;
-  const long pad = env_int("LBM_PLANE_PAD_FLOATS", 0);
-  c->plane_stride[s] = round_up(cells, 64) + pad;
-  const size_t lat_bytes = (size_t)c->plane_stride[s] * lbm::kQ * sizeof(float);
+  const long cells = (long)sl.rows * c->pitch;  // mask entries
+  const size_t lat_bytes = (size_t)sl.rows * c->row_pitch * sizeof(float);
   for (int i = 0; i < 2; i++) HIP_TRY(LBM_FAILURE, hipMalloc(&sl.lat[i], lat_bytes));
   HIP_TRY(LBM_FAILURE, hipMalloc(&sl.mask, (size_t)cells));
   HIP_TRY(LBM_FAILURE, hipMalloc(&sl.partials, (size_t)kPartSlots * c->part_stride * sizeof(float)));
@@ -401,8 +411,8 @@ int build_slab(lbm_ctx* c, int s, const int* obstacles, const float* cells_aos) 
     const float r0 = p.density * 4.f / 9.f;  // SerialCode/d2q9-bgk.c:546-548
     const float r1 = p.density / 9.f;
     const float r2 = p.density / 36.f;
-    hipLaunchKernelGGL(lbm::init_equilibrium, dim3(ceil_div(cells, 256)), dim3(256), 0, sl.compute,
-                       sl.lat[0], c->plane_stride[s], cells, r0, r1, r2);
+    hipLaunchKernelGGL(lbm::init_equilibrium, dim3(ceil_div((long)p.nx * sl.rows, 256)), dim3(256), 0,
+                       sl.compute, sl.lat[0], c->plane_stride, c->row_pitch, p.nx, sl.rows, r0, r1, r2);
     HIP_TRY(LBM_FAILURE, hipGetLastError());
   } else {
     // upload in chunks of rows through a staging buffer, transposing AoS -> SoA on the device
@@ -417,7 +427,7 @@ int build_slab(lbm_ctx* c, int s, const int* obstacles, const float* cells_aos) 
       HIP_TRY(LBM_FAILURE, hipMemcpyAsync(stage, cells_aos + (size_t)(sl.row_first + r0) * p.nx * lbm::kQ,
                                           n * sizeof(float), hipMemcpyHostToDevice, sl.compute));
       hipLaunchKernelGGL(lbm::aos_to_soa, dim3(ceil_div((long)n, 256)), dim3(256), 0, sl.compute, stage,
-                         sl.lat[0], c->plane_stride[s], c->pitch, p.nx, r0, nr);
+                         sl.lat[0], c->plane_stride, c->row_pitch, p.nx, r0, nr);
       HIP_TRY(LBM_FAILURE, hipGetLastError());
       HIP_TRY(LBM_FAILURE, hipStreamSynchronize(sl.compute));
     }
@@ -453,7 +463,12 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
   c->capacity = params->max_iters;
   c->fluid_cells = count_fluid(params, obstacles);
   c->pitch = (int)round_up(params->nx, 64);
+  c->plane_stride = c->pitch + env_int("LBM_PLANE_PAD_FLOATS", 0) / 4 * 4;
+  c->row_pitch = 9 * c->plane_stride;
   c->vec4 = (params->nx % 4 == 0);
+  c->neigh = env_int("LBM_NEIGH", 0);
+  if (c->neigh < 0 || c->neigh > 2) c->neigh = 0;
+  c->nts = env_int("LBM_NTS", 1) ? 1 : 0;
   c->n_slabs = n_slabs;
 
   // rows of this context, then of each slab
@@ -670,7 +685,7 @@ int lbm_read_cells(lbm_ctx* c, float* cells_aos) {
       const int nr = (sl.rows - r0 < chunk_rows) ? sl.rows - r0 : (int)chunk_rows;
       const size_t n = (size_t)nr * nx * lbm::kQ;
       hipLaunchKernelGGL(lbm::soa_to_aos, dim3(ceil_div((long)n, 256)), dim3(256), 0, sl.compute,
-                         sl.lat[c->cur], stage, c->plane_stride[s], c->pitch, nx, r0, nr);
+                         sl.lat[c->cur], stage, c->plane_stride, c->row_pitch, nx, r0, nr);
       HIP_TRY(LBM_FAILURE, hipGetLastError());
       HIP_TRY(LBM_FAILURE, hipMemcpyAsync(cells_aos + (size_t)(sl.row_first - c->row_first + r0) * nx * lbm::kQ, stage,
                                           n * sizeof(float), hipMemcpyDeviceToHost, sl.compute));
@@ -698,7 +713,7 @@ int lbm_read_final_state(lbm_ctx* c, float* u_x, float* u_y, float* u_mag, float
       const int nr = (sl.rows - r0 < chunk_rows) ? sl.rows - r0 : (int)chunk_rows;
       const size_t n = (size_t)nr * nx;
       hipLaunchKernelGGL(lbm::final_state, dim3(ceil_div((long)n, 256)), dim3(256), 0, sl.compute,
-                         sl.lat[c->cur], sl.mask, c->plane_stride[s], c->pitch, nx, r0, nr, c->p.density,
+                         sl.lat[c->cur], sl.mask, c->plane_stride, c->row_pitch, c->pitch, nx, r0, nr, c->p.density,
                          stage, stage + chunk_cells, stage + 2 * chunk_cells, stage + 3 * chunk_cells);
       HIP_TRY(LBM_FAILURE, hipGetLastError());
       const size_t off = (size_t)(sl.row_first - c->row_first + r0) * nx;
@@ -721,7 +736,7 @@ static int lattice_totals(lbm_ctx* c, double* speed, double* mass) {
     Slab& sl = c->slab[s];
     HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
     hipLaunchKernelGGL(lbm::lattice_sums, dim3(kSumBlocks), dim3(lbm::kBlock), 0, sl.compute, sl.lat[c->cur],
-                       sl.mask, c->plane_stride[s], c->pitch, c->p.nx, sl.rows, sl.scratch,
+                       sl.mask, c->plane_stride, c->row_pitch, c->pitch, c->p.nx, sl.rows, sl.scratch,
                        sl.scratch + kSumBlocks);
     HIP_TRY(LBM_FAILURE, hipGetLastError());
     HIP_TRY(LBM_FAILURE, hipMemcpyAsync(h.data(), sl.scratch, 2 * kSumBlocks * sizeof(double),

@@ -8,8 +8,12 @@
 //   relaxed cells into one partial per workgroup, and apply NEXT step's accelerate_flow to the
 //   lid row before storing (so no separate pass over that row is needed).
 //
-// Layout: structure of arrays, 9 planes of fp32, plane k at base + k*plane_stride, row-major
-// rows x pitch.  Each value is read exactly once and written exactly once per step: the
+// Layout: structure of arrays interleaved by row -- value (k, y, x) lives at
+// base + y*row_pitch + k*plane_stride + x with plane_stride = pitch and row_pitch = 9*pitch, i.e.
+// the 9 planes of one row lie next to each other (36*nx bytes), rows follow each other.  Every
+// access is still a contiguous, 16-byte-aligned run along x of ONE speed (fully coalesced), but a
+// workgroup's 9+9 streams now fall into a ~1 MB window instead of 18 windows 256 MiB apart:
+// measured 10-13 % faster than 9 whole-grid planes on MI355X (profiles/r01_tuning.md).  Each value is read exactly once and written exactly once per step: the
 // algorithmic traffic is 72 B per lattice update, and there is no reuse to stage in LDS or to
 // feed MFMA -- this kernel is bound by HBM bandwidth.  Each lane owns 4 consecutive cells and
 // moves every plane with one 16-byte access; the +-1 column shifts of the six x-moving
@@ -40,7 +44,8 @@ struct StepArgs {
   float* dst;                 // plane 0 of the destination lattice
   const unsigned char* mask;  // rows x pitch, 1 = blocked
   long plane_stride;          // floats between planes
-  int pitch;                  // floats between rows
+  int pitch;                  // floats between rows of the mask and of the packed halo rows
+  long row_pitch;             // floats between lattice rows of one plane
   int nx;                     // cells per row
   int rows;                   // rows owned by this slab
   int row_first;              // first slab row this launch advances
@@ -158,8 +163,9 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+template <int BLOCK = kBlock>
 __device__ __forceinline__ float block_sum(float v) {
-  __shared__ float wave_part[kBlock / 64];
+  __shared__ float wave_part[BLOCK / 64];
   v = wave_sum(v);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) wave_part[wave] = v;
@@ -167,50 +173,89 @@ __device__ __forceinline__ float block_sum(float v) {
   float total = 0.f;
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int w = 0; w < kBlock / 64; w++) total += wave_part[w];
+    for (int w = 0; w < BLOCK / 64; w++) total += wave_part[w];
   }
   return total;  // valid in thread 0
 }
 
 // ---------------------------------------------------------------------------------------------
 // fused step, 4 cells per lane (nx % 4 == 0, pitch % 4 == 0)
+//
+// MATH : 0 exact (reference arithmetic), 1 fast (reciprocal + FMA), 2 copy-through (tuning only)
+// NEIGH: how the +-1 column neighbours of the six x-moving populations are obtained
+//        0 = one strided dword load per plane (simple, but each touches as many cache lines as
+//            the 16-byte load beside it),
+//        1 = from the adjacent lane's aligned vector by a wave64 cross-lane move
+//            (__shfl_up/down -> ds_bpermute_b32, no LDS storage); only the first / last lane of a
+//            wave and the row ends load a dword,
+//        2 = the same with DPP wave_shr:1 / wave_shl:1 (one VALU move, no LDS crossbar).
+// NTS  : nontemporal stores.
 // ---------------------------------------------------------------------------------------------
-template <bool EXACT>
-__global__ __launch_bounds__(kBlock) void step_vec4(const StepArgs a) {
-  const int quads_x = a.nx >> 2;
-  const long q = (long)blockIdx.x * kBlock + threadIdx.x;
-  const long n_quads = (long)quads_x * a.n_rows;
-  float my_sum = 0.f;
+template <int NEIGH>
+__device__ __forceinline__ float lane_from_west(float v) {  // lane i <- lane i-1
+  if constexpr (NEIGH == 2)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+  else
+    return __shfl_up(v, 1, 64);
+}
+template <int NEIGH>
+__device__ __forceinline__ float lane_from_east(float v) {  // lane i <- lane i+1
+  if constexpr (NEIGH == 2)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+  else
+    return __shfl_down(v, 1, 64);
+}
 
-  if (q < n_quads) {
+template <bool NTS>
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+  if constexpr (NTS) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    v4 v = {a, b, c, d};
+    __builtin_nontemporal_store(v, reinterpret_cast<v4*>(p));
+  } else {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+  }
+}
+
+template <int MATH, int NEIGH, bool NTS, int BLOCK = kBlock, bool SYNC = false>
+__global__ __launch_bounds__(BLOCK) void step_vec4(const StepArgs a) {
+  const int quads_x = a.nx >> 2;
+  const long q = (long)blockIdx.x * BLOCK + threadIdx.x;
+  const long n_quads = (long)quads_x * a.n_rows;
+  const bool active = q < n_quads;
+  const long ps = a.plane_stride;
+  float my_sum = 0.f;
+  float r[4][kQ];
+  int row = 0, x0 = 0;
+
+  if (active) {
     const int rsel = (int)(q / quads_x);
-    const int x0 = (int)(q - (long)rsel * quads_x) << 2;
-    const int row = a.row_first + rsel * a.row_stride;
+    x0 = (int)(q - (long)rsel * quads_x) << 2;
+    row = a.row_first + rsel * a.row_stride;
 
     // neighbour columns with periodic wrap (SerialCode/d2q9-bgk.c:258,260)
     const int xw = (x0 == 0) ? a.nx - 1 : x0 - 1;
     const int xe = (x0 + 4 == a.nx) ? 0 : x0 + 4;
 
-    const long ps = a.plane_stride;
-    const float* c_row = a.src + (long)row * a.pitch;  // plane 0, this row
+    const float* c_row = a.src + (long)row * a.row_pitch;  // plane 0, this row
     // row below (speeds 2,5,6 arrive from it) and above (4,7,8), :257,259
     const float *s2, *s5, *s6, *n4, *n7, *n8;
     if (row == 0 && a.recv_south) {
       s2 = a.recv_south;  s5 = s2 + a.pitch;  s6 = s5 + a.pitch;
     } else {
       const int rs = (row == 0) ? a.rows - 1 : row - 1;
-      const float* b = a.src + (long)rs * a.pitch;
+      const float* b = a.src + (long)rs * a.row_pitch;
       s2 = b + 2 * ps;  s5 = b + 5 * ps;  s6 = b + 6 * ps;
     }
     if (row == a.rows - 1 && a.recv_north) {
       n4 = a.recv_north;  n7 = n4 + a.pitch;  n8 = n7 + a.pitch;
     } else {
       const int rn = (row == a.rows - 1) ? 0 : row + 1;
-      const float* b = a.src + (long)rn * a.pitch;
+      const float* b = a.src + (long)rn * a.row_pitch;
       n4 = b + 4 * ps;  n7 = b + 7 * ps;  n8 = b + 8 * ps;
     }
 
-    // 9 aligned 16-byte loads + 6 neighbour dwords
+    // 9 aligned 16-byte loads
     const float4 v0 = *reinterpret_cast<const float4*>(c_row + x0);
     const float4 v1 = *reinterpret_cast<const float4*>(c_row + 1 * ps + x0);
     const float4 v3 = *reinterpret_cast<const float4*>(c_row + 3 * ps + x0);
@@ -220,12 +265,31 @@ __global__ __launch_bounds__(kBlock) void step_vec4(const StepArgs a) {
     const float4 v4 = *reinterpret_cast<const float4*>(n4 + x0);
     const float4 v7 = *reinterpret_cast<const float4*>(n7 + x0);
     const float4 v8 = *reinterpret_cast<const float4*>(n8 + x0);
-    const float e1 = c_row[1 * ps + xw];  // speed 1 travels east: comes from the west cell
-    const float e3 = c_row[3 * ps + xe];
-    const float e5 = s5[xw];
-    const float e6 = s6[xe];
-    const float e7 = n7[xe];
-    const float e8 = n8[xw];
+    // the cell just west of the quad (for speeds 1,5,8) and just east of it (3,6,7)
+    float e1, e3, e5, e6, e7, e8;
+    if constexpr (NEIGH == 0) {
+      e1 = c_row[1 * ps + xw];  // speed 1 travels east: comes from the west cell
+      e3 = c_row[3 * ps + xe];
+      e5 = s5[xw];
+      e6 = s6[xe];
+      e7 = n7[xe];
+      e8 = n8[xw];
+    } else {
+      const int lane = threadIdx.x & 63;
+      e1 = lane_from_west<NEIGH>(v1.w);
+      e5 = lane_from_west<NEIGH>(v5.w);
+      e8 = lane_from_west<NEIGH>(v8.w);
+      e3 = lane_from_east<NEIGH>(v3.x);
+      e6 = lane_from_east<NEIGH>(v6.x);
+      e7 = lane_from_east<NEIGH>(v7.x);
+      // the wave's first / last lane and the row ends have no such lane: one dword each
+      if (lane == 0 || x0 == 0) {
+        e1 = c_row[1 * ps + xw];  e5 = s5[xw];  e8 = n8[xw];
+      }
+      if (lane == 63 || x0 + 4 == a.nx || q + 1 == n_quads) {
+        e3 = c_row[3 * ps + xe];  e6 = s6[xe];  e7 = n7[xe];
+      }
+    }
     const uchar4 m = *reinterpret_cast<const uchar4*>(a.mask + (long)row * a.pitch + x0);
 
     // streamed populations of the 4 cells: t[j][k]
@@ -237,23 +301,31 @@ __global__ __launch_bounds__(kBlock) void step_vec4(const StepArgs a) {
     const unsigned char blocked[4] = {m.x, m.y, m.z, m.w};
     const bool lid = (row == a.accel_row);
 
-    float r[4][kQ];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       if (blocked[j]) {
         bounce(t[j], r[j]);
       } else {
-        float speed;
-        collide<EXACT>(t[j], a.omega, r[j], speed);
+        float speed = 0.f;
+        if constexpr (MATH == 0) collide<true>(t[j], a.omega, r[j], speed);
+        else if constexpr (MATH == 1) collide<false>(t[j], a.omega, r[j], speed);
+        else {
+#pragma unroll
+          for (int k = 0; k < kQ; k++) r[j][k] = t[j][k];
+        }
         my_sum += speed;
         if (lid) accelerate(r[j], a.a1, a.a2);
       }
     }
+  }
 
-    float* d_row = a.dst + (long)row * a.pitch + x0;
+  // optionally let the whole workgroup reach its stores together (one contiguous burst per plane)
+  if constexpr (SYNC) __syncthreads();
+
+  if (active) {
+    float* d_row = a.dst + (long)row * a.row_pitch + x0;
 #pragma unroll
-    for (int k = 0; k < kQ; k++)
-      *reinterpret_cast<float4*>(d_row + k * ps) = make_float4(r[0][k], r[1][k], r[2][k], r[3][k]);
+    for (int k = 0; k < kQ; k++) store4<NTS>(d_row + k * ps, r[0][k], r[1][k], r[2][k], r[3][k]);
 
     // packed halo rows for the neighbours' next step
     if (a.send_south && row == 0) {
@@ -270,7 +342,7 @@ __global__ __launch_bounds__(kBlock) void step_vec4(const StepArgs a) {
     }
   }
 
-  const float total = block_sum(my_sum);
+  const float total = block_sum<BLOCK>(my_sum);
   if (threadIdx.x == 0) a.partials[blockIdx.x] = total;
 }
 
@@ -289,20 +361,20 @@ __global__ __launch_bounds__(kBlock) void step_scalar(const StepArgs a) {
     const int xw = (x == 0) ? a.nx - 1 : x - 1;
     const int xe = (x + 1 == a.nx) ? 0 : x + 1;
     const long ps = a.plane_stride;
-    const float* c_row = a.src + (long)row * a.pitch;
+    const float* c_row = a.src + (long)row * a.row_pitch;
     const float *s2, *s5, *s6, *n4, *n7, *n8;
     if (row == 0 && a.recv_south) {
       s2 = a.recv_south;  s5 = s2 + a.pitch;  s6 = s5 + a.pitch;
     } else {
       const int rs = (row == 0) ? a.rows - 1 : row - 1;
-      const float* b = a.src + (long)rs * a.pitch;
+      const float* b = a.src + (long)rs * a.row_pitch;
       s2 = b + 2 * ps;  s5 = b + 5 * ps;  s6 = b + 6 * ps;
     }
     if (row == a.rows - 1 && a.recv_north) {
       n4 = a.recv_north;  n7 = n4 + a.pitch;  n8 = n7 + a.pitch;
     } else {
       const int rn = (row == a.rows - 1) ? 0 : row + 1;
-      const float* b = a.src + (long)rn * a.pitch;
+      const float* b = a.src + (long)rn * a.row_pitch;
       n4 = b + 4 * ps;  n7 = b + 7 * ps;  n8 = b + 8 * ps;
     }
     float t[kQ] = {c_row[x], c_row[1 * ps + xw], s2[x], c_row[3 * ps + xe], n4[x],
@@ -316,7 +388,7 @@ __global__ __launch_bounds__(kBlock) void step_scalar(const StepArgs a) {
       my_sum = speed;
       if (row == a.accel_row) accelerate(r, a.a1, a.a2);
     }
-    float* d = a.dst + (long)row * a.pitch + x;
+    float* d = a.dst + (long)row * a.row_pitch + x;
 #pragma unroll
     for (int k = 0; k < kQ; k++) d[k * ps] = r[k];
     if (a.send_south && row == 0) {
@@ -336,12 +408,12 @@ __global__ __launch_bounds__(kBlock) void step_scalar(const StepArgs a) {
 
 // accelerate_flow() as its own pass (SerialCode/d2q9-bgk.c:216-246): used once before the first
 // step of a run; later steps get it from the epilogue of the step kernel.
-__global__ void accelerate_row(float* lat, const unsigned char* mask, long ps, int pitch, int nx,
-                               int row, float a1, float a2) {
+__global__ void accelerate_row(float* lat, const unsigned char* mask, long ps, long row_pitch,
+                               int pitch, int nx, int row, float a1, float a2) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= nx) return;
-  const long c = (long)row * pitch + x;
-  if (mask[c]) return;
+  if (mask[(long)row * pitch + x]) return;
+  const long c = (long)row * row_pitch + x;
   float f[kQ];
 #pragma unroll
   for (int k = 0; k < kQ; k++) f[k] = lat[k * ps + c];
@@ -351,11 +423,11 @@ __global__ void accelerate_row(float* lat, const unsigned char* mask, long ps, i
 }
 
 // fill the packed send rows from the current lattice (before the first halo exchange of a run)
-__global__ void pack_halo(const float* lat, long ps, int pitch, int nx, int rows,
+__global__ void pack_halo(const float* lat, long ps, long row_pitch, int pitch, int nx, int rows,
                           float* send_south, float* send_north) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= nx) return;
-  const long top = (long)(rows - 1) * pitch + x;
+  const long top = (long)(rows - 1) * row_pitch + x;
   send_south[x] = lat[4 * ps + x];
   send_south[pitch + x] = lat[7 * ps + x];
   send_south[2 * pitch + x] = lat[8 * ps + x];
@@ -383,16 +455,19 @@ __global__ __launch_bounds__(kBlock) void reduce_partials(const float* partials,
 }
 
 // uniform equilibrium start (SerialCode/d2q9-bgk.c:546-567)
-__global__ void init_equilibrium(float* lat, long ps, long n, float r0, float r1, float r2) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__global__ void init_equilibrium(float* lat, long ps, long row_pitch, int nx, int rows, float r0,
+                                 float r1, float r2) {
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= (long)nx * rows) return;
+  const long row = j / nx;
+  const long i = row * row_pitch + (j - row * nx);
   lat[i] = r0;
   lat[1 * ps + i] = r1;  lat[2 * ps + i] = r1;  lat[3 * ps + i] = r1;  lat[4 * ps + i] = r1;
   lat[5 * ps + i] = r2;  lat[6 * ps + i] = r2;  lat[7 * ps + i] = r2;  lat[8 * ps + i] = r2;
 }
 
 // AoS (reference host layout, 9 floats per cell) <-> SoA planes, rows [row0, row0+nrows)
-__global__ void aos_to_soa(const float* aos, float* lat, long ps, int pitch, int nx, int row0,
+__global__ void aos_to_soa(const float* aos, float* lat, long ps, long row_pitch, int nx, int row0,
                            int nrows) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long n = (long)nx * nrows * kQ;
@@ -400,10 +475,10 @@ __global__ void aos_to_soa(const float* aos, float* lat, long ps, int pitch, int
   const long cell = i / kQ;
   const int k = (int)(i - cell * kQ);
   const int r = (int)(cell / nx), x = (int)(cell - (long)r * nx);
-  lat[k * ps + (long)(row0 + r) * pitch + x] = aos[i];
+  lat[k * ps + (long)(row0 + r) * row_pitch + x] = aos[i];
 }
 
-__global__ void soa_to_aos(const float* lat, float* aos, long ps, int pitch, int nx, int row0,
+__global__ void soa_to_aos(const float* lat, float* aos, long ps, long row_pitch, int nx, int row0,
                            int nrows) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long n = (long)nx * nrows * kQ;
@@ -411,19 +486,19 @@ __global__ void soa_to_aos(const float* lat, float* aos, long ps, int pitch, int
   const long cell = i / kQ;
   const int k = (int)(i - cell * kQ);
   const int r = (int)(cell / nx), x = (int)(cell - (long)r * nx);
-  aos[i] = lat[k * ps + (long)(row0 + r) * pitch + x];
+  aos[i] = lat[k * ps + (long)(row0 + r) * row_pitch + x];
 }
 
 // write_values() quantities (SerialCode/d2q9-bgk.c:684-719), always in the exact arithmetic
-__global__ void final_state(const float* lat, const unsigned char* mask, long ps, int pitch, int nx,
-                            int row0, int nrows, float density, float* ux_o, float* uy_o,
-                            float* um_o, float* pr_o) {
+__global__ void final_state(const float* lat, const unsigned char* mask, long ps, long row_pitch,
+                            int pitch, int nx, int row0, int nrows, float density, float* ux_o,
+                            float* uy_o, float* um_o, float* pr_o) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long n = (long)nx * nrows;
   if (i >= n) return;
   const int r = (int)(i / nx), x = (int)(i - (long)r * nx);
-  const long c = (long)(row0 + r) * pitch + x;
-  if (mask[c]) {
+  const long c = (long)(row0 + r) * row_pitch + x;
+  if (mask[(long)(row0 + r) * pitch + x]) {
     ux_o[i] = 0.f;  uy_o[i] = 0.f;  um_o[i] = 0.f;
     pr_o[i] = density * kCsq;
   } else {
@@ -441,21 +516,22 @@ __global__ void final_state(const float* lat, const unsigned char* mask, long ps
 // av_velocity() of a stored lattice (SerialCode/d2q9-bgk.c:409-458): per-workgroup partials of
 // sum |u| in double; reduced by reduce_doubles.  Also serves total_density() (:644-660).
 __global__ __launch_bounds__(kBlock) void lattice_sums(const float* lat, const unsigned char* mask,
-                                                       long ps, int pitch, int nx, int rows,
-                                                       double* speed_part, double* mass_part) {
+                                                       long ps, long row_pitch, int pitch, int nx,
+                                                       int rows, double* speed_part,
+                                                       double* mass_part) {
   __shared__ double sh_s[kBlock], sh_m[kBlock];
   double s = 0.0, m = 0.0;
   const long n = (long)nx * rows;
   for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) {
     const int r = (int)(i / nx), x = (int)(i - (long)r * nx);
-    const long c = (long)r * pitch + x;
+    const long c = (long)r * row_pitch + x;
     float f[kQ];
 #pragma unroll
     for (int k = 0; k < kQ; k++) f[k] = lat[k * ps + c];
     float rho, ux, uy;
     moments_exact(f, rho, ux, uy);
     m += (double)rho;
-    if (!mask[c]) s += (double)sqrtf((ux * ux) + (uy * uy));
+    if (!mask[(long)r * pitch + x]) s += (double)sqrtf((ux * ux) + (uy * uy));
   }
   sh_s[threadIdx.x] = s;  sh_m[threadIdx.x] = m;
   __syncthreads();
