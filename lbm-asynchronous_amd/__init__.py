@@ -161,11 +161,19 @@ class Engine:
                  world_size: int | None = None, unique_id: bytes | None = None, device: int = 0):
         self.lib = load_library()
         self.params = params
-        obstacles = np.ascontiguousarray(obstacles, dtype=np.int32).reshape(params.ny, params.nx)
+        if params.nx < 1 or params.ny < 2 or params.max_iters < 0:
+            raise LbmError("lbm_create: invalid parameters")
+        obstacles = np.ascontiguousarray(obstacles, dtype=np.int32)
+        if obstacles.size != params.nx * params.ny:
+            raise LbmError("lbm_create: obstacle map does not match nx*ny")
+        obstacles = obstacles.reshape(params.ny, params.nx)
         self._obstacles = obstacles
         cptr = None
         if cells is not None:
-            cells = np.ascontiguousarray(cells, dtype=np.float32).reshape(params.ny, params.nx, 9)
+            cells = np.ascontiguousarray(cells, dtype=np.float32)
+            if cells.size != params.nx * params.ny * 9:
+                raise LbmError("lbm_create: cells do not match nx*ny*9")
+            cells = cells.reshape(params.ny, params.nx, 9)
             cptr = cells.ctypes.data
         cp = params._c()
         if rank is None:

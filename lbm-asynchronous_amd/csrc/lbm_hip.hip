@@ -571,7 +571,7 @@ int lbm_partition_rows(int ny, int parts, int index, int* first, int* count) {
   const int base = ny / parts, rem = ny % parts;
   const int cnt = base + (index < rem ? 1 : 0);
   const int fst = index * base + (index < rem ? index : rem);
-  if (parts > 1 && cnt < 2)
+  if (parts > 1 && base < 2)  // some part (not necessarily this one) would be too thin
     LBM_FAIL(LBM_FAILURE, "lbm_partition_rows: %d rows over %d parts leaves a part with fewer than 2 rows", ny, parts);
   if (first) *first = fst;
   if (count) *count = cnt;

@@ -1,0 +1,90 @@
+"""CPU checks of the C-ABI boundary: the shared library loads, exports exactly what
+include/lbm_hip.h declares, and its host-only entry points behave (no compute without a GPU)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "lbm_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lbm_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(lbm):
+    lib = ctypes.CDLL(lbm.LIB_PATH)
+    declared = header_symbols()
+    assert declared, "no prototypes found in include/lbm_hip.h"
+    for name in declared:
+        assert hasattr(lib, name), f"liblbm_hip.so does not export {name}"
+    assert sorted(lbm.ABI_SYMBOLS) == declared, "binding symbol list out of date with the header"
+
+
+def test_exported_symbols_are_plain_c(lbm):
+    """extern "C": the dynamic symbol table holds the unmangled names."""
+    out = subprocess.run(["nm", "-D", "--defined-only", lbm.LIB_PATH], capture_output=True, text=True)
+    names = {line.split()[-1] for line in out.stdout.splitlines() if line.strip()}
+    for name in header_symbols():
+        assert name in names
+
+
+def test_version_and_device_count(lbm):
+    lib = lbm.load_library()
+    assert lib.lbm_version().decode().startswith("lbm_hip")
+    assert lbm.device_count() >= 0
+
+
+@pytest.mark.parametrize("ny,parts", [(128, 1), (128, 8), (8192, 8), (23, 4), (16384, 7), (16, 8)])
+def test_partition_rows_covers_grid(lbm, ny, parts):
+    seen = []
+    for i in range(parts):
+        first, count = lbm.partition_rows(ny, parts, i)
+        assert count >= (2 if parts > 1 else 1)
+        seen.append((first, count))
+    assert seen[0][0] == 0
+    for (f0, c0), (f1, _) in zip(seen, seen[1:]):
+        assert f0 + c0 == f1
+    assert seen[-1][0] + seen[-1][1] == ny
+    counts = [c for _, c in seen]
+    assert max(counts) - min(counts) <= 1
+
+
+def test_partition_rows_rejects_thin_slabs(lbm):
+    with pytest.raises(lbm.LbmError):
+        lbm.partition_rows(9, 8, 0)
+    with pytest.raises(lbm.LbmError):
+        lbm.partition_rows(128, 0, 0)
+
+
+def test_create_fails_loudly_without_device_or_with_bad_args(lbm, datasets):
+    """No CPU fallback: on a box without a GPU lbm_create must fail, not compute."""
+    p, ob = datasets("128x128")
+    if lbm.device_count() == 0:
+        with pytest.raises(lbm.LbmError, match="no HIP device"):
+            lbm.Engine(p, ob)
+    bad = lbm.Params(0, 128, 10, 10, 0.1, 0.005, 1.85)
+    with pytest.raises(lbm.LbmError):
+        lbm.Engine(bad, ob)
+    with pytest.raises(lbm.LbmError):
+        lbm.Engine(p, ob, n_gpus=99)
+
+
+def test_die_mode_matches_reference_message_shape(lbm):
+    """Default error mode = the reference's die(): 'Error at line N of file F:' + message, exit 1
+    (SerialCode/d2q9-bgk.c:745-751).  Checked in a child process."""
+    code = (
+        "import ctypes,sys\n"
+        f"lib=ctypes.CDLL({lbm.LIB_PATH!r})\n"
+        "lib.lbm_partition_rows.argtypes=[ctypes.c_int]*3+[ctypes.c_void_p]*2\n"
+        "lib.lbm_partition_rows(9,8,0,None,None)\n"
+        "print('survived')\n")
+    out = subprocess.run(["python3", "-c", code], capture_output=True, text=True)
+    assert out.returncode == 1
+    assert "survived" not in out.stdout
+    assert re.search(r"^Error at line \d+ of file .*:\n.*fewer than 2 rows", out.stderr, flags=re.M)
