@@ -1,0 +1,139 @@
+"""End-to-end runs on the GPU at the reference's full sizes, through the C host program.
+
+* the four reference data sets at their full iteration counts with the command line
+  `d2q9-bgk <paramfile> <obstaclefile>`: `final_state.dat` must be BYTE-IDENTICAL to the file the
+  reference's SerialCode binary wrote (md5 recorded in tests/golden/serialcode_*.npz), and both
+  output files must pass the check.py rule (<= 1 %) against the reference's double-precision
+  goldens where those exist (check/*.dat; tests/golden/check_goldens.npz);
+* BASELINE.json's 8192x8192 synthetic grid: a short run compared bit for bit with the CPU oracle's
+  multi-threaded fused form, plus size-independent properties (mass conservation, zero velocity
+  in blocked cells, run-splitting invariance).
+"""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def md5(path):
+    h = hashlib.md5()
+    with open(path, "rb") as fh:
+        for blk in iter(lambda: fh.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+@pytest.mark.parametrize("name", ["128x128", "128x256", "256x256", "1024x1024"])
+def test_cli_full_run_matches_serialcode_bytes_and_goldens(lbm, tmp_path, name):
+    if not os.path.exists(lbm.CLI_PATH):
+        lbm.build()
+    pf = os.path.join(GOLDEN, "inputs", f"input_{name}.params")
+    of = os.path.join(GOLDEN, "inputs", f"obstacles_{name}.dat")
+    out = subprocess.run([lbm.CLI_PATH, pf, of], cwd=tmp_path, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines()
+    assert lines[0] == "==done==" and lines[1].startswith("Reynolds number:\t\t")
+
+    ref = np.load(os.path.join(GOLDEN, f"serialcode_{name}.npz"))
+    gold = np.load(os.path.join(GOLDEN, "check_goldens.npz"))
+
+    # final_state.dat: the very bytes SerialCode writes
+    assert md5(tmp_path / "final_state.dat") == str(ref["md5_final_state"])
+
+    # av_vels.dat: same format, values within summation-order noise of SerialCode's
+    av = np.loadtxt(tmp_path / "av_vels.dat", usecols=[1])
+    assert av.size == ref["av_vels"].size
+    np.testing.assert_allclose(av, ref["av_vels"].astype(np.float64), rtol=5e-4)
+    # Reynolds number printed = calc_reynolds on the final lattice (:196, :637-642)
+    re_printed = float(lines[1].split()[-1])
+    assert re_printed == pytest.approx(float(ref["reynolds"]), rel=5e-4)
+
+    # the reference's acceptance gate against its own goldens (check/check.py, tolerance 1 %)
+    assert lbm.check_passes(gold[f"av_vels_{name}"], av)
+    if f"pressure_{name}" in gold:
+        pr = np.loadtxt(tmp_path / "final_state.dat", usecols=[5])
+        assert lbm.check_passes(gold[f"pressure_{name}"], pr)
+
+
+def test_fast_mode_full_run_passes_check_rule(lbm, datasets, golden):
+    """FAST arithmetic over a full 40 000-step run still passes check.py's 1 % gate against the
+    double-precision goldens and against SerialCode's fp32 output."""
+    p, ob = datasets("128x128")
+    gold = np.load(os.path.join(golden, "check_goldens.npz"))
+    ref = np.load(os.path.join(golden, "serialcode_128x128.npz"))
+    with lbm.Engine(p, ob, None, math="fast") as eng:
+        eng.run(p.max_iters)
+        av = eng.av_vels()
+        pr = eng.final_state()["pressure"]
+    assert lbm.check_passes(gold["av_vels_128x128"], av)
+    assert lbm.check_passes(gold["pressure_128x128"], pr)
+    assert lbm.check_passes(ref["av_vels"], av) and lbm.check_passes(ref["pressure"], pr)
+
+
+@pytest.fixture(scope="module")
+def big_case(lbm):
+    tile = lbm.read_obstacles(os.path.join(GOLDEN, "inputs", "obstacles_1024x1024.dat"), 1024, 1024)
+    ob = lbm.tile_obstacles(tile, 8192, 8192)
+    p = lbm.Params(8192, 8192, 64, 10, 0.1, 0.01, 1.85)
+    return p, ob
+
+
+def test_8192_short_run_bitwise_vs_oracle(lbm, oracle, big_case):
+    """BASELINE.json config 3 (synthetic 8192x8192, 1024x1024 obstacles tiled 8x8): 6 steps against
+    the oracle's multi-threaded fused form; lattice and pressure bit-identical, av_vels by the
+    check.py rule (big-grid parity through binary fields, not text files)."""
+    p, ob = big_case
+    steps = 6
+    src = np.empty((9, p.ny, p.nx), dtype=np.float32)
+    w = np.float32(p.density)
+    src[0] = w * np.float32(4.0) / np.float32(9.0)
+    src[1:5] = w / np.float32(9.0)
+    src[5:9] = w / np.float32(36.0)
+    dst = np.empty_like(src)
+    fluid = np.float32((ob == 0).sum())
+    ref_av = []
+    for _ in range(steps):
+        ref_av.append(np.float32(oracle.fused_step_periodic(p, src, dst, ob)) / fluid)
+        src, dst = dst, src
+    del dst
+    with lbm.Engine(p, ob, None) as eng:
+        eng.run(steps)
+        got_av = eng.av_vels(steps)
+        got = eng.cells()                      # (ny, nx, 9)
+        fields = eng.final_state()
+    for k in range(9):
+        assert np.array_equal(got[:, :, k].view(np.uint32), src[k].view(np.uint32)), f"speed {k}"
+    assert lbm.check_passes(np.array(ref_av), got_av)
+    np.testing.assert_allclose(got_av, np.array(ref_av, dtype=np.float32), rtol=2e-3)
+    rho = src[0].copy()
+    for k in range(1, 9):
+        rho += src[k]                          # same left-to-right fp32 order as the reference
+    want_p = np.where(ob == 1, np.float32(p.density) * np.float32(1.0 / 3.0), rho * np.float32(1.0 / 3.0))
+    assert np.array_equal(fields["pressure"].view(np.uint32), want_p.astype(np.float32).view(np.uint32))
+    assert not fields["u"][ob == 1].any()
+
+
+def test_8192_properties(lbm, big_case):
+    p, ob = big_case
+    with lbm.Engine(p, ob, None) as eng, lbm.Engine(p, ob, None) as split:
+        m0 = eng.total_density()
+        assert m0 == pytest.approx(0.1 * 8192 * 8192, rel=1e-6)
+        eng.run(40)
+        # mass is conserved (the reference's DEBUG invariant, SerialCode/d2q9-bgk.c:175-179)
+        assert eng.total_density() == pytest.approx(m0, rel=1e-6)
+        av = eng.av_vels(40)
+        assert np.isfinite(av).all() and (av > 0).all() and (np.diff(av) > 0).all()
+        # splitting the run changes nothing, bit for bit
+        for n in (1, 7, 32):
+            split.run(n)
+        assert np.array_equal(split.av_vels(40), av)
+        assert eng.av_velocity() == pytest.approx(float(av[-1]), rel=1e-6)
+        a = eng.final_state()["pressure"]
+        b = split.final_state()["pressure"]
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
