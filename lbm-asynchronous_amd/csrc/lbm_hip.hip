@@ -82,6 +82,8 @@ struct Slab {
   float* recv_north = nullptr;
   hipStream_t compute = nullptr, comm = nullptr;
   hipEvent_t ev_boundary = nullptr, ev_halo = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+  hipEvent_t ev_interior[2] = {nullptr, nullptr};  // interior kernel of step t -> [t & 1]
+  hipEvent_t ev_flush = nullptr;                   // partials reduced: their slots may be reused
   ncclComm_t nccl = nullptr;
   int blocks_main = 0;      // interior rows (or all rows in HALO_SELF)
   int blocks_boundary = 0;  // rows 0 and rows-1 (halo modes)
@@ -105,6 +107,7 @@ struct lbm_ctx {
   int math_mode = LBM_MATH_EXACT;
   int halo = HALO_SELF;
   int rank = 0, world = 1;  // multi-process
+  bool ranked = false;      // created by lbm_create_rank (owns an ncclCommInitRank communicator)
   int row_first = 0, row_count = 0;
   int slot_fill = 0;  // partial slots used since the last reduce
   long part_stride = 0;
@@ -116,8 +119,8 @@ struct lbm_ctx {
 namespace {
 
 // ---- launch helpers --------------------------------------------------------------------------
-int launch_step(lbm_ctx* c, int s, int row_first, int row_stride, int n_rows, int part_offset,
-                bool accel_epilogue) {
+int launch_step(lbm_ctx* c, int s, hipStream_t stream, int row_first, int row_stride, int n_rows,
+                int part_offset, bool accel_epilogue) {
   Slab& sl = c->slab[s];
   if (n_rows <= 0) return LBM_SUCCESS;
   lbm::StepArgs a;
@@ -155,11 +158,11 @@ int launch_step(lbm_ctx* c, int s, int row_first, int row_stride, int n_rows, in
         {{lbm::step_vec4<1, 0, false>, lbm::step_vec4<1, 0, true>},
          {lbm::step_vec4<1, 1, false>, lbm::step_vec4<1, 1, true>},
          {lbm::step_vec4<1, 2, false>, lbm::step_vec4<1, 2, true>}}};
-    hipLaunchKernelGGL(table[exact ? 0 : 1][c->neigh][c->nts], dim3(blocks), dim3(lbm::kBlock), 0, sl.compute, a);
+    hipLaunchKernelGGL(table[exact ? 0 : 1][c->neigh][c->nts], dim3(blocks), dim3(lbm::kBlock), 0, stream, a);
   } else {
     const int blocks = ceil_div((long)c->p.nx * n_rows, lbm::kBlock);
-    if (exact) hipLaunchKernelGGL(lbm::step_scalar<true>, dim3(blocks), dim3(lbm::kBlock), 0, sl.compute, a);
-    else       hipLaunchKernelGGL(lbm::step_scalar<false>, dim3(blocks), dim3(lbm::kBlock), 0, sl.compute, a);
+    if (exact) hipLaunchKernelGGL(lbm::step_scalar<true>, dim3(blocks), dim3(lbm::kBlock), 0, stream, a);
+    else       hipLaunchKernelGGL(lbm::step_scalar<false>, dim3(blocks), dim3(lbm::kBlock), 0, stream, a);
   }
   HIP_TRY(LBM_FAILURE, hipGetLastError());
   return LBM_SUCCESS;
@@ -171,23 +174,19 @@ int blocks_for_rows(const lbm_ctx* c, int n_rows) {
                  : ceil_div((long)c->p.nx * n_rows, lbm::kBlock);
 }
 
-// One halo exchange: every slab's packed send rows travel to its ring neighbours' recv rows.
-// north neighbour of slab s = s+1 (periodic), south = s-1; across processes the ring runs over
-// ranks (MPI/d2q9-bgk.c:210-211).
+// One halo exchange, enqueued on the comm streams: every slab's packed send rows travel to its
+// ring neighbours' recv rows.  north neighbour of slab s = s+1 (periodic), south = s-1; across
+// processes the ring runs over ranks (MPI/d2q9-bgk.c:210-211).
+// Precondition (stream order): the kernel that filled the send rows was enqueued on the same comm
+// stream (boundary kernel), or the comm stream already waits for it (first exchange of a run).
 int exchange_halos(lbm_ctx* c) {
   const long n = 3L * c->pitch;
   if (c->halo == HALO_RCCL) {
-    // comm stream waits for the boundary kernel that filled the send rows
-    for (int s = 0; s < c->n_slabs; s++) {
-      Slab& sl = c->slab[s];
-      HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
-      HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sl.ev_boundary, 0));
-    }
     NCCL_TRY(LBM_FAILURE, ncclGroupStart());
     for (int s = 0; s < c->n_slabs; s++) {
       Slab& sl = c->slab[s];
       int me, parts;
-      if (c->world > 1) { me = c->rank; parts = c->world; } else { me = s; parts = c->n_slabs; }
+      if (c->ranked) { me = c->rank; parts = c->world; } else { me = s; parts = c->n_slabs; }
       const int north = (me + 1) % parts, south = (me - 1 + parts) % parts;
       // order matters when north == south (2 parts): first send pairs with the peer's first recv
       NCCL_TRY(LBM_FAILURE, ncclSend(sl.send_north, n, ncclFloat, north, sl.nccl, sl.comm));
@@ -196,20 +195,14 @@ int exchange_halos(lbm_ctx* c) {
       NCCL_TRY(LBM_FAILURE, ncclRecv(sl.recv_north, n, ncclFloat, north, sl.nccl, sl.comm));
     }
     NCCL_TRY(LBM_FAILURE, ncclGroupEnd());
-    for (int s = 0; s < c->n_slabs; s++) {
-      Slab& sl = c->slab[s];
-      HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
-      HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_halo, sl.comm));
-    }
   } else if (c->halo == HALO_MEMCPY) {
-    // push model inside one process: slab s copies its send rows into its neighbours' recv rows.
-    // It may do so once its own boundary kernel (send rows written) and the neighbours' boundary
-    // kernels (their recv rows consumed) have finished.
+    // push model inside one process: slab s copies its send rows into its neighbours' recv rows
+    // once the neighbours' boundary kernels have consumed the previous contents (ev_boundary);
+    // the neighbours' next boundary kernels wait for ev_halo of the pushing slabs.
     for (int s = 0; s < c->n_slabs; s++) {
       Slab& sl = c->slab[s];
       const int north = (s + 1) % c->n_slabs, south = (s - 1 + c->n_slabs) % c->n_slabs;
       HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
-      HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sl.ev_boundary, 0));
       HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, c->slab[north].ev_boundary, 0));
       HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, c->slab[south].ev_boundary, 0));
       HIP_TRY(LBM_FAILURE, hipMemcpyAsync(c->slab[north].recv_south, sl.send_north, n * sizeof(float),
@@ -222,32 +215,38 @@ int exchange_halos(lbm_ctx* c) {
   return LBM_SUCCESS;
 }
 
-// the compute stream of slab s must not start its boundary rows before the halos have landed
-int wait_halos(lbm_ctx* c, int s) {
-  Slab& sl = c->slab[s];
-  HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, sl.ev_halo, 0));
-  if (c->halo == HALO_MEMCPY) {
-    const int north = (s + 1) % c->n_slabs, south = (s - 1 + c->n_slabs) % c->n_slabs;
-    HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, c->slab[north].ev_halo, 0));
-    HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, c->slab[south].ev_halo, 0));
-  }
-  return LBM_SUCCESS;
-}
-
 // reduce the buffered per-workgroup partials of the last slot_fill steps into tot_u[step_base...]
 int flush_partials(lbm_ctx* c, int step_base) {
   if (c->slot_fill == 0) return LBM_SUCCESS;
   for (int s = 0; s < c->n_slabs; s++) {
     Slab& sl = c->slab[s];
     HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+    // the boundary rows' partials are written on the comm stream
+    if (c->halo != HALO_SELF) HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, sl.ev_boundary, 0));
     hipLaunchKernelGGL(lbm::reduce_partials, dim3(c->slot_fill), dim3(lbm::kBlock), 0, sl.compute,
                        sl.partials, sl.blocks_main + sl.blocks_boundary, c->part_stride, sl.tot_u,
                        step_base);
     HIP_TRY(LBM_FAILURE, hipGetLastError());
+    if (c->halo != HALO_SELF) {
+      // the next boundary kernels (comm stream) reuse the partial slots just read
+      HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_flush, sl.compute));
+      HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sl.ev_flush, 0));
+    }
   }
   return LBM_SUCCESS;
 }
 
+// The timestep loop.  Single slab: one fused launch per step.  Several slabs / ranks
+// (the Waitall pattern of MPI_Waitall/d2q9-bgk.c:225-253, restructured for two HIP streams):
+//
+//   compute stream:  I(0) ─────────────► I(1) ─────────────► I(2) ...     interior rows 1..rows-2
+//                      ▲ waits B(t-1)      ▲
+//   comm stream:     X(0) → B(0) → X(1) → B(1) → X(2) → B(2) ...          halo exchange, boundary rows
+//                            ▲ waits I(t-1)
+//
+// I(t) and B(t) both read lattice t and write disjoint rows of lattice t+1; B(t) additionally
+// needs the halos X(t) (its own stream, in order) and writes the packed rows X(t+1) sends.  The
+// chain of interior kernels is the critical path; exchange and boundary rows hide beside it.
 int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
   if (!c) LBM_FAIL(LBM_FAILURE, "lbm_run: null context");
   if (n_steps < 0) LBM_FAIL(LBM_FAILURE, "lbm_run: negative step count");
@@ -267,16 +266,21 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
     HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
     if (sl.accel_row >= 0) {
       hipLaunchKernelGGL(lbm::accelerate_row, dim3(ceil_div(c->p.nx, 256)), dim3(256), 0, sl.compute,
-                         sl.lat[c->cur], sl.mask, c->plane_stride, c->row_pitch, c->pitch, c->p.nx, sl.accel_row,
-                         a1, a2);
+                         sl.lat[c->cur], sl.mask, c->plane_stride, c->row_pitch, c->pitch, c->p.nx,
+                         sl.accel_row, a1, a2);
       HIP_TRY(LBM_FAILURE, hipGetLastError());
     }
     if (halo) {
       hipLaunchKernelGGL(lbm::pack_halo, dim3(ceil_div(c->p.nx, 256)), dim3(256), 0, sl.compute,
-                         sl.lat[c->cur], c->plane_stride, c->row_pitch, c->pitch, c->p.nx, sl.rows, sl.send_south,
-                         sl.send_north);
+                         sl.lat[c->cur], c->plane_stride, c->row_pitch, c->pitch, c->p.nx, sl.rows,
+                         sl.send_south, sl.send_north);
       HIP_TRY(LBM_FAILURE, hipGetLastError());
-      HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_boundary, sl.compute));
+      // "I(-1)": lattice and packed rows are ready; also orders the comm stream after everything
+      // a previous lbm_run left on the compute stream
+      HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_interior[1], sl.compute));
+      HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sl.ev_interior[1], 0));
+      // boundary event in a defined state for the first memcpy exchange
+      HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_boundary, sl.comm));
     }
   }
   if (halo && exchange_halos(c) != LBM_SUCCESS) return LBM_FAILURE;
@@ -290,25 +294,31 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
   int flushed_upto = c->steps_done;
   for (int t = 0; t < n_steps; t++) {
     const bool last = (t == n_steps - 1);
+    // interior rows (or the whole slab) on the compute streams
     for (int s = 0; s < c->n_slabs; s++) {
       Slab& sl = c->slab[s];
       HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
       if (!halo) {
-        if (launch_step(c, s, 0, 1, sl.rows, 0, !last) != LBM_SUCCESS) return LBM_FAILURE;
+        if (launch_step(c, s, sl.compute, 0, 1, sl.rows, 0, !last) != LBM_SUCCESS) return LBM_FAILURE;
       } else {
-        // interior rows need no halo: they overlap with the exchange in flight
-        if (launch_step(c, s, 1, 1, sl.rows - 2, 0, !last) != LBM_SUCCESS) return LBM_FAILURE;
+        if (t > 0) HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, sl.ev_boundary, 0));  // B(t-1)
+        if (launch_step(c, s, sl.compute, 1, 1, sl.rows - 2, 0, !last) != LBM_SUCCESS) return LBM_FAILURE;
+        HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_interior[t & 1], sl.compute));
       }
     }
     if (halo) {
+      // boundary rows 0 and rows-1 on the comm streams, behind the exchange X(t)
       for (int s = 0; s < c->n_slabs; s++) {
         Slab& sl = c->slab[s];
         HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
-        if (wait_halos(c, s) != LBM_SUCCESS) return LBM_FAILURE;
-        // boundary rows 0 and rows-1 (the Waitall-then-boundary pattern,
-        // MPI_Waitall/d2q9-bgk.c:243-253)
-        if (launch_step(c, s, 0, sl.rows - 1, 2, sl.blocks_main, !last) != LBM_SUCCESS) return LBM_FAILURE;
-        HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_boundary, sl.compute));
+        HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sl.ev_interior[(t + 1) & 1], 0));  // I(t-1)
+        if (c->halo == HALO_MEMCPY) {
+          const int north = (s + 1) % c->n_slabs, south = (s - 1 + c->n_slabs) % c->n_slabs;
+          HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, c->slab[north].ev_halo, 0));
+          HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, c->slab[south].ev_halo, 0));
+        }
+        if (launch_step(c, s, sl.comm, 0, sl.rows - 1, 2, sl.blocks_main, !last) != LBM_SUCCESS) return LBM_FAILURE;
+        HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_boundary, sl.comm));
       }
       if (!last && exchange_halos(c) != LBM_SUCCESS) return LBM_FAILURE;
     }
@@ -321,6 +331,7 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
     }
   }
   c->steps_done += n_steps;
+  // (the last flush made every compute stream wait for its final boundary kernel)
 
   if (kernel_ms) {
     float worst = 0.f;
@@ -356,6 +367,8 @@ void free_slab(Slab& sl) {
   if (sl.recv_north) (void)hipFree(sl.recv_north);
   if (sl.ev_boundary) (void)hipEventDestroy(sl.ev_boundary);
   if (sl.ev_halo) (void)hipEventDestroy(sl.ev_halo);
+  for (int i = 0; i < 2; i++) if (sl.ev_interior[i]) (void)hipEventDestroy(sl.ev_interior[i]);
+  if (sl.ev_flush) (void)hipEventDestroy(sl.ev_flush);
   if (sl.ev_t0) (void)hipEventDestroy(sl.ev_t0);
   if (sl.ev_t1) (void)hipEventDestroy(sl.ev_t1);
   if (sl.compute) (void)hipStreamDestroy(sl.compute);
@@ -376,6 +389,9 @@ int build_slab(lbm_ctx* c, int s, const int* obstacles, const float* cells_aos) 
   HIP_TRY(LBM_FAILURE, hipStreamCreateWithFlags(&sl.comm, hipStreamNonBlocking));
   HIP_TRY(LBM_FAILURE, hipEventCreateWithFlags(&sl.ev_boundary, hipEventDisableTiming));
   HIP_TRY(LBM_FAILURE, hipEventCreateWithFlags(&sl.ev_halo, hipEventDisableTiming));
+  for (int i = 0; i < 2; i++) HIP_TRY(LBM_FAILURE, hipEventCreateWithFlags(&sl.ev_interior[i], hipEventDisableTiming));
+  HIP_TRY(LBM_FAILURE, hipEventCreateWithFlags(&sl.ev_flush, hipEventDisableTiming));
+  HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_halo, sl.comm));
   HIP_TRY(LBM_FAILURE, hipEventCreate(&sl.ev_t0));
   HIP_TRY(LBM_FAILURE, hipEventCreate(&sl.ev_t1));
 
@@ -477,7 +493,8 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
     return nullptr;
   }
   const bool force_halo = env_int("LBM_FORCE_HALO", 0) != 0;
-  if (world > 1) c->halo = HALO_RCCL;
+  c->ranked = (unique_id != nullptr);
+  if (world > 1 || (c->ranked && force_halo)) c->halo = HALO_RCCL;
   else if (n_slabs > 1 || force_halo) {
     const char* h = getenv("LBM_HALO");
     bool distinct = (n_slabs <= ndev);
@@ -494,7 +511,7 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
       delete c;
       return nullptr;
     }
-    sl.device = (world > 1) ? device : (s % ndev);
+    sl.device = c->ranked ? device : (s % ndev);
     sl.row_first = c->row_first + first;
     sl.rows = count;
     const int lid = params->ny - 2;  // SerialCode/d2q9-bgk.c:223
@@ -521,27 +538,26 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
       return nullptr;
     }
 
-  if (c->halo == HALO_RCCL) {
-    if (world > 1) {
-      ncclUniqueId id;
-      memcpy(&id, unique_id, sizeof(id));
-      if (hipSetDevice(c->slab[0].device) != hipSuccess ||
-          ncclCommInitRank(&c->slab[0].nccl, world, id, rank) != ncclSuccess) {
-        raise_error(__LINE__, "lbm_create_rank: ncclCommInitRank failed");
-        lbm_destroy(c);
-        return nullptr;
-      }
-    } else {
-      ncclComm_t comms[kMaxSlabs];
-      int devs[kMaxSlabs];
-      for (int s = 0; s < n_slabs; s++) devs[s] = c->slab[s].device;
-      if (ncclCommInitAll(comms, n_slabs, devs) != ncclSuccess) {
-        raise_error(__LINE__, "lbm_create: ncclCommInitAll failed (set LBM_HALO=memcpy when slabs share a device)");
-        lbm_destroy(c);
-        return nullptr;
-      }
-      for (int s = 0; s < n_slabs; s++) c->slab[s].nccl = comms[s];
+  if (c->ranked) {
+    // one process per GPU: the communicator spans the ranks (also used for the av_vels reduce)
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    if (hipSetDevice(c->slab[0].device) != hipSuccess ||
+        ncclCommInitRank(&c->slab[0].nccl, world, id, rank) != ncclSuccess) {
+      raise_error(__LINE__, "lbm_create_rank: ncclCommInitRank failed");
+      lbm_destroy(c);
+      return nullptr;
     }
+  } else if (c->halo == HALO_RCCL) {
+    ncclComm_t comms[kMaxSlabs];
+    int devs[kMaxSlabs];
+    for (int s = 0; s < n_slabs; s++) devs[s] = c->slab[s].device;
+    if (ncclCommInitAll(comms, n_slabs, devs) != ncclSuccess) {
+      raise_error(__LINE__, "lbm_create: ncclCommInitAll failed (set LBM_HALO=memcpy when slabs share a device)");
+      lbm_destroy(c);
+      return nullptr;
+    }
+    for (int s = 0; s < n_slabs; s++) c->slab[s].nccl = comms[s];
   }
   return c;
 }
@@ -595,7 +611,7 @@ int lbm_rccl_unique_id(void* id_out) {
 lbm_ctx* lbm_create_rank(const lbm_params* params, const int* obstacles, const float* cells_aos,
                          int rank, int world_size, const void* unique_id, int device, int math_mode) {
   if (world_size < 1 || rank < 0 || rank >= world_size) LBM_FAIL(nullptr, "lbm_create_rank: bad rank %d of %d", rank, world_size);
-  if (world_size > 1 && !unique_id) LBM_FAIL(nullptr, "lbm_create_rank: unique_id is NULL");
+  if (!unique_id) LBM_FAIL(nullptr, "lbm_create_rank: unique_id is NULL");
   return create_common(params, obstacles, cells_aos, 1, math_mode, rank, world_size, unique_id, device);
 }
 
@@ -653,7 +669,7 @@ int lbm_read_av_vels(lbm_ctx* c, float* out, int n) {
     HIP_TRY(LBM_FAILURE, hipMemcpy(part.data(), c->slab[s].tot_u, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     for (int t = 0; t < n; t++) total[(size_t)t] += part[(size_t)t];
   }
-  if (c->world > 1) {
+  if (c->ranked) {
     // the reference's MPI_Reduce(av_vels, SUM) (MPI/d2q9-bgk.c:298-309), as an all-reduce
     Slab& sl = c->slab[0];
     double* tmp = nullptr;
@@ -744,7 +760,7 @@ static int lattice_totals(lbm_ctx* c, double* speed, double* mass) {
     HIP_TRY(LBM_FAILURE, hipStreamSynchronize(sl.compute));
     for (int i = 0; i < kSumBlocks; i++) { tot[0] += h[i]; tot[1] += h[kSumBlocks + i]; }
   }
-  if (c->world > 1) {
+  if (c->ranked) {
     Slab& sl = c->slab[0];
     HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
     HIP_TRY(LBM_FAILURE, hipMemcpy(sl.scratch, tot, 2 * sizeof(double), hipMemcpyHostToDevice));

@@ -155,6 +155,23 @@ def test_rccl_self_exchange(lbm, oracle, datasets, monkeypatch):
     np.testing.assert_allclose(got_av, ref_av, rtol=AV_RTOL)
 
 
+def test_rank_api_single_rank_rccl(lbm, oracle, datasets, monkeypatch):
+    """lbm_create_rank with a world of one: ncclCommInitRank, halo send/recv to itself and the
+    av_vels all-reduce all run through RCCL -- the code path every rank of a torchrun job takes."""
+    monkeypatch.setenv("LBM_FORCE_HALO", "1")
+    p, ob = datasets("128x256")
+    cells = oracle.init_cells(p)
+    ref = cells.copy()
+    ref_av = oracle.run(p, ref, ob, 45)
+    with lbm.Engine(p, ob, cells, rank=0, world_size=1, unique_id=lbm.rccl_unique_id(), device=0) as eng:
+        info = eng.info()
+        assert (info["world_rank"], info["world_size"], info["row_first"], info["row_count"]) == (0, 1, 0, p.ny)
+        eng.run(45)
+        assert np.array_equal(eng.cells().view(np.uint32), ref.view(np.uint32))
+        np.testing.assert_allclose(eng.av_vels(45), ref_av, rtol=AV_RTOL)
+        assert eng.av_velocity() == pytest.approx(float(ref_av[-1]), rel=AV_RTOL)
+
+
 def test_fast_mode_within_check_tolerance(lbm, oracle, datasets):
     p, ob = datasets("128x128")
     cells = oracle.init_cells(p)
