@@ -114,6 +114,7 @@ struct lbm_ctx {
   bool vec4 = false;
   int neigh = 0;  // step_vec4 NEIGH flavour (LBM_NEIGH overrides)
   int nts = 1;    // nontemporal stores (LBM_NTS overrides)
+  int snake = 0;  // alternate the sweep direction every step (LBM_SNAKE overrides)
 };
 
 namespace {
@@ -140,6 +141,7 @@ int launch_step(lbm_ctx* c, int s, hipStream_t stream, int row_first, int row_st
   a.a1 = c->p.density * c->p.accel / 9.f;   // SerialCode/d2q9-bgk.c:219
   a.a2 = c->p.density * c->p.accel / 36.f;  // :220
   a.partials = sl.partials + (long)c->slot_fill * c->part_stride + part_offset;
+  a.reverse = (c->snake && n_rows > 2) ? (c->cur & 1) : 0;
   const bool halo = (c->halo != HALO_SELF);
   a.recv_south = halo ? sl.recv_south : nullptr;
   a.recv_north = halo ? sl.recv_north : nullptr;
@@ -484,7 +486,11 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
   c->vec4 = (params->nx % 4 == 0);
   c->neigh = env_int("LBM_NEIGH", 0);
   if (c->neigh < 0 || c->neigh > 2) c->neigh = 0;
-  c->nts = env_int("LBM_NTS", 1) ? 1 : 0;
+  // nontemporal stores pay once the two lattices no longer fit the 256 MiB Infinity Cache
+  // (measured: +4 % at 4096^2 and above, -2..-20 % at 2048^2 and below; profiles/r01_tuning.md)
+  const double lattice_pair_bytes = 2.0 * 36.0 * (double)params->nx * (double)params->ny;
+  c->nts = env_int("LBM_NTS", lattice_pair_bytes > 512.0 * 1024 * 1024 ? 1 : 0) ? 1 : 0;
+  c->snake = env_int("LBM_SNAKE", 0) ? 1 : 0;
   c->n_slabs = n_slabs;
 
   // rows of this context, then of each slab

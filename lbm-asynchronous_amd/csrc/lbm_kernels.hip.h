@@ -55,6 +55,7 @@ struct StepArgs {
   float omega;
   float a1, a2;               // density*accel/9, density*accel/36 (SerialCode/d2q9-bgk.c:219-220)
   float* partials;            // one fp32 partial sum of |u| per workgroup of this launch
+  int reverse;                // 1: workgroup b handles tile (n_tiles-1-b): rows are swept top-down
   // packed halo rows (NULL in the single-slab periodic case):
   const float* recv_south;    // 3 x pitch: planes 2,5,6 of the row below slab row 0
   const float* recv_north;    // 3 x pitch: planes 4,7,8 of the row above slab row rows-1
@@ -220,8 +221,11 @@ __device__ __forceinline__ void store4(float* p, float a, float b, float c, floa
 template <int MATH, int NEIGH, bool NTS, int BLOCK = kBlock, bool SYNC = false>
 __global__ __launch_bounds__(BLOCK) void step_vec4(const StepArgs a) {
   const int quads_x = a.nx >> 2;
-  const long q = (long)blockIdx.x * BLOCK + threadIdx.x;
   const long n_quads = (long)quads_x * a.n_rows;
+  // alternate the sweep direction from step to step: the rows written last by the previous step
+  // (still in L2 / Infinity Cache) are then the first ones read
+  const long tile = a.reverse ? (long)(gridDim.x - 1 - blockIdx.x) : (long)blockIdx.x;
+  const long q = tile * BLOCK + threadIdx.x;
   const bool active = q < n_quads;
   const long ps = a.plane_stride;
   float my_sum = 0.f;

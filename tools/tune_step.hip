@@ -94,6 +94,7 @@ struct Variant {
   const char* name;
   kern_t k;
   int block = kBlock;
+  int snake = 0;
 };
 
 int main(int argc, char** argv) {
@@ -123,19 +124,10 @@ int main(int argc, char** argv) {
   };
 
   std::vector<Variant> vars = {
-      {"exact loads b256     ", step_vec4<0, 0, false, 256, false>, 256},
-      {"exact loads b256 sync", step_vec4<0, 0, false, 256, true>, 256},
-      {"exact loads b512     ", step_vec4<0, 0, false, 512, false>, 512},
-      {"exact loads b512 sync", step_vec4<0, 0, false, 512, true>, 512},
-      {"exact loads b1024    ", step_vec4<0, 0, false, 1024, false>, 1024},
-      {"exact loads b1024sync", step_vec4<0, 0, false, 1024, true>, 1024},
-      {"exact lds nt b256    ", step_vec4<0, 0, true, 256, false>, 256},
-      {"exact lds nt b256sync", step_vec4<0, 0, true, 256, true>, 256},
-      {"exact lds nt b512sync", step_vec4<0, 0, true, 512, true>, 512},
-      {"exact lds nt b1024syn", step_vec4<0, 0, true, 1024, true>, 1024},
-      {"exact dpp nt b512sync", step_vec4<0, 2, true, 512, true>, 512},
-      {"probe 9planes        ", probe<false, false, false, false>, 256},
-      {"probe +rows+sum      ", probe<true, false, false, true>, 256},
+      {"exact loads nt       ", step_vec4<0, 0, true, 256, false>, 256},
+      {"exact loads          ", step_vec4<0, 0, false, 256, false>, 256},
+      {"exact loads nt  snake", step_vec4<0, 0, true, 256, false>, 256, 1},
+      {"exact loads     snake", step_vec4<0, 0, false, 256, false>, 256, 1},
   };
   std::vector<long> pads = {0, 320, 1088, 8256};
   std::vector<int> occs = {0};  // 0 = no cap; k = at most k workgroups (4 waves each) per CU
@@ -198,12 +190,12 @@ int main(int argc, char** argv) {
         const int grid = (int)(((long)(nx / 4) * ny + v.block - 1) / v.block);
         float* L[2] = {A, B + boff};
         for (int i = 0; i < 2; i++) {
-          a.src = L[i & 1]; a.dst = L[(i & 1) ^ 1];
+          a.src = L[i & 1]; a.dst = L[(i & 1) ^ 1]; a.reverse = v.snake ? (i & 1) : 0;
           hipLaunchKernelGGL(v.k, dim3(grid), dim3(v.block), dyn_lds, 0, a);
         }
         CK(hipEventRecord(e0));
         for (int i = 0; i < iters; i++) {
-          a.src = L[i & 1]; a.dst = L[(i & 1) ^ 1];
+          a.src = L[i & 1]; a.dst = L[(i & 1) ^ 1]; a.reverse = v.snake ? (i & 1) : 0;
           hipLaunchKernelGGL(v.k, dim3(grid), dim3(v.block), dyn_lds, 0, a);
         }
         CK(hipEventRecord(e1));
