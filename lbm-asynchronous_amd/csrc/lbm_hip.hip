@@ -19,7 +19,7 @@
 namespace {
 
 constexpr int kMaxSlabs = 8;
-constexpr int kPartSlots = 64;  // steps whose partial sums are buffered before one reduce launch
+constexpr int kPartSlots = lbm::kPartSlotsMax;  // steps whose partial sums are buffered before one reduce launch
 
 enum HaloMode { HALO_SELF = 0, HALO_MEMCPY = 1, HALO_RCCL = 2 };
 
@@ -115,6 +115,9 @@ struct lbm_ctx {
   int neigh = 0;  // step_vec4 NEIGH flavour (LBM_NEIGH overrides)
   int nts = 1;    // nontemporal stores (LBM_NTS overrides)
   int snake = 0;  // alternate the sweep direction every step (LBM_SNAKE overrides)
+  int fuse2 = 0;  // two timesteps per pass (step2_stream) when a single periodic slab allows it
+  int band_rows = 64, n_strips = 0, n_bands = 0;  // step2_stream geometry
+  lbm::SlotCounts slot_counts;  // partials written into each buffered slot
 };
 
 namespace {
@@ -167,6 +170,44 @@ int launch_step(lbm_ctx* c, int s, hipStream_t stream, int row_first, int row_st
     else       hipLaunchKernelGGL(lbm::step_scalar<false>, dim3(blocks), dim3(lbm::kBlock), 0, stream, a);
   }
   HIP_TRY(LBM_FAILURE, hipGetLastError());
+  return LBM_SUCCESS;
+}
+
+// two timesteps in one pass (single periodic slab): writes the partials of steps t and t+1 into
+// slots slot_fill and slot_fill+1
+int launch_step2(lbm_ctx* c, bool accel_after) {
+  Slab& sl = c->slab[0];
+  lbm::Step2Args a;
+  a.src = sl.lat[c->cur];
+  a.dst = sl.lat[c->cur ^ 1];
+  a.mask = sl.mask;
+  a.plane_stride = c->plane_stride;
+  a.row_pitch = c->row_pitch;
+  a.pitch = c->pitch;
+  a.nx = c->p.nx;
+  a.rows = sl.rows;
+  a.band_rows = c->band_rows;
+  a.n_strips = c->n_strips;
+  a.accel_row = sl.accel_row;
+  a.accel_after = accel_after ? 1 : 0;
+  a.omega = c->p.omega;
+  a.a1 = c->p.density * c->p.accel / 9.f;
+  a.a2 = c->p.density * c->p.accel / 36.f;
+  a.partials1 = sl.partials + (long)c->slot_fill * c->part_stride;
+  a.partials2 = a.partials1 + c->part_stride;
+  const int waves = c->n_strips * c->n_bands;
+  typedef void (*fn)(const lbm::Step2Args);
+  static const fn table[2][2][2] = {
+      {{lbm::step2_stream<0, false, false>, lbm::step2_stream<0, false, true>},
+       {lbm::step2_stream<0, true, false>, lbm::step2_stream<0, true, true>}},
+      {{lbm::step2_stream<1, false, false>, lbm::step2_stream<1, false, true>},
+       {lbm::step2_stream<1, true, false>, lbm::step2_stream<1, true, true>}}};
+  static const int prefetch = env_int("LBM_PREFETCH", 1) ? 1 : 0;
+  hipLaunchKernelGGL(table[c->math_mode == LBM_MATH_EXACT ? 0 : 1][c->nts][prefetch], dim3(waves), dim3(64), 0,
+                     sl.compute, a);
+  HIP_TRY(LBM_FAILURE, hipGetLastError());
+  c->slot_counts.n[c->slot_fill] = waves;
+  c->slot_counts.n[c->slot_fill + 1] = waves;
   return LBM_SUCCESS;
 }
 
@@ -226,8 +267,7 @@ int flush_partials(lbm_ctx* c, int step_base) {
     // the boundary rows' partials are written on the comm stream
     if (c->halo != HALO_SELF) HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, sl.ev_boundary, 0));
     hipLaunchKernelGGL(lbm::reduce_partials, dim3(c->slot_fill), dim3(lbm::kBlock), 0, sl.compute,
-                       sl.partials, sl.blocks_main + sl.blocks_boundary, c->part_stride, sl.tot_u,
-                       step_base);
+                       sl.partials, c->slot_counts, c->part_stride, sl.tot_u, step_base);
     HIP_TRY(LBM_FAILURE, hipGetLastError());
     if (c->halo != HALO_SELF) {
       // the next boundary kernels (comm stream) reuse the partial slots just read
@@ -295,6 +335,20 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
 
   int flushed_upto = c->steps_done;
   for (int t = 0; t < n_steps; t++) {
+    // two steps per pass where possible (single periodic slab, vector kernel)
+    if (c->fuse2 && !halo && t + 1 < n_steps) {
+      HIP_TRY(LBM_FAILURE, hipSetDevice(c->slab[0].device));
+      if (launch_step2(c, /*accel_after=*/t + 2 < n_steps) != LBM_SUCCESS) return LBM_FAILURE;
+      c->cur ^= 1;
+      c->slot_fill += 2;
+      t += 1;
+      if (c->slot_fill >= kPartSlots - 1 || t == n_steps - 1) {
+        if (flush_partials(c, flushed_upto) != LBM_SUCCESS) return LBM_FAILURE;
+        flushed_upto += c->slot_fill;
+        c->slot_fill = 0;
+      }
+      continue;
+    }
     const bool last = (t == n_steps - 1);
     // interior rows (or the whole slab) on the compute streams
     for (int s = 0; s < c->n_slabs; s++) {
@@ -324,9 +378,10 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
       }
       if (!last && exchange_halos(c) != LBM_SUCCESS) return LBM_FAILURE;
     }
+    c->slot_counts.n[c->slot_fill] = c->slab[0].blocks_main + c->slab[0].blocks_boundary;
     c->cur ^= 1;
     c->slot_fill++;
-    if (c->slot_fill == kPartSlots || last) {
+    if (c->slot_fill >= kPartSlots - 1 || last) {
       if (flush_partials(c, flushed_upto) != LBM_SUCCESS) return LBM_FAILURE;
       flushed_upto += c->slot_fill;
       c->slot_fill = 0;
@@ -536,6 +591,13 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
     }
     if (sl.blocks_main + sl.blocks_boundary > max_blocks) max_blocks = sl.blocks_main + sl.blocks_boundary;
   }
+  // two-steps-per-pass geometry (single periodic slab only)
+  c->band_rows = env_int("LBM_BAND_ROWS", 64);
+  if (c->band_rows < 1) c->band_rows = 1;
+  c->n_strips = ceil_div(params->nx / 4 > 0 ? params->nx / 4 : 1, lbm::kStripQuads);
+  c->n_bands = ceil_div(c->row_count, c->band_rows);
+  c->fuse2 = (c->halo == HALO_SELF && c->vec4 && env_int("LBM_FUSE2", 0)) ? 1 : 0;
+  if (c->fuse2 && c->n_strips * c->n_bands > max_blocks) max_blocks = c->n_strips * c->n_bands;
   c->part_stride = round_up(max_blocks, 64);
 
   for (int s = 0; s < n_slabs; s++)

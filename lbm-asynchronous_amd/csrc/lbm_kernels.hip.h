@@ -409,6 +409,213 @@ __global__ __launch_bounds__(BLOCK) void step_vec4(const StepArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// TWO timesteps per pass over memory (temporal blocking), single slab, periodic in x and y.
+//
+// The one-step kernel above sits at the float4-copy ceiling of the chip (72 B per update cannot
+// move faster).  The only way past that roofline is to move fewer bytes: this kernel advances the
+// lattice by two steps while reading it once and writing it once (36 B per update).
+//
+// One WAVE (64 lanes, no LDS, no barrier) owns a vertical strip of 62 quads (248 cells; lanes 0
+// and 63 are halo quads that only feed their neighbours) and sweeps a band of rows upwards.
+// Per row iteration it
+//   1. pulls row r of the source lattice and relaxes it            -> step t   results N (registers)
+//   2. relaxes row r-1 a second time from a sliding window of step-t results kept in registers:
+//        speeds 2,5,6 of row r-2, speeds 0,1,3 of row r-1, speeds 4,7,8 of row r (= N);
+//      the +-1 column neighbours come from the adjacent lanes (DPP wave_shr:1 / wave_shl:1)
+//                                                                   -> step t+1 results, stored
+//   3. rotates the window.
+// Every step-t value is consumed exactly once, so the window is 36 floats per lane and nothing
+// is staged in LDS.  Redundant work: 2 of 64 lanes and 2 warm-up rows per band.
+// Per-cell arithmetic is the same code as the one-step kernel: results stay bit-identical.
+//
+// accelerate_flow: step t+1's acceleration is applied to the step-t results of the lid row
+// (always); step t+2's to the stored results when accel_after != 0 (not on the last step of a run).
+// ---------------------------------------------------------------------------------------------
+struct Step2Args {
+  const float* src;
+  float* dst;
+  const unsigned char* mask;
+  long plane_stride;
+  long row_pitch;
+  int pitch;
+  int nx;
+  int rows;        // grid rows (periodic)
+  int band_rows;   // output rows per wave
+  int n_strips;    // waves across x
+  int accel_row;
+  int accel_after;
+  float omega, a1, a2;
+  float* partials1;  // per wave: sum |u| after step t   (own cells only)
+  float* partials2;  // per wave: sum |u| after step t+1
+};
+
+constexpr int kStripQuads = 62;  // output quads per wave (lanes 1..62)
+
+template <int MATH>
+__device__ __forceinline__ void relax_cell(const float (&t)[kQ], bool blocked, bool lid, float omega, float a1,
+                                           float a2, float (&r)[kQ], float& speed) {
+  speed = 0.f;
+  if (blocked) {
+    bounce(t, r);
+  } else {
+    if constexpr (MATH == 0) collide<true>(t, omega, r, speed);
+    else collide<false>(t, omega, r, speed);
+    if (lid) accelerate(r, a1, a2);
+  }
+}
+
+// the 9 aligned vectors, 6 neighbour dwords and mask bytes one lane pulls for one row
+struct RowPull {
+  float4 v0, v1, v2, v3, v4, v5, v6, v7, v8;
+  uchar4 m;
+};
+
+__device__ __forceinline__ RowPull pull_row(const Step2Args& a, int r, int x0) {
+  const long ps = a.plane_stride;
+  const int rs = (r == 0) ? a.rows - 1 : r - 1;
+  const int rn = (r == a.rows - 1) ? 0 : r + 1;
+  const float* c_row = a.src + (long)r * a.row_pitch;
+  const float* sb = a.src + (long)rs * a.row_pitch;
+  const float* nb = a.src + (long)rn * a.row_pitch;
+  RowPull p;
+  p.v0 = *reinterpret_cast<const float4*>(c_row + x0);
+  p.v1 = *reinterpret_cast<const float4*>(c_row + 1 * ps + x0);
+  p.v3 = *reinterpret_cast<const float4*>(c_row + 3 * ps + x0);
+  p.v2 = *reinterpret_cast<const float4*>(sb + 2 * ps + x0);
+  p.v5 = *reinterpret_cast<const float4*>(sb + 5 * ps + x0);
+  p.v6 = *reinterpret_cast<const float4*>(sb + 6 * ps + x0);
+  p.v4 = *reinterpret_cast<const float4*>(nb + 4 * ps + x0);
+  p.v7 = *reinterpret_cast<const float4*>(nb + 7 * ps + x0);
+  p.v8 = *reinterpret_cast<const float4*>(nb + 8 * ps + x0);
+  p.m = *reinterpret_cast<const uchar4*>(a.mask + (long)r * a.pitch + x0);
+  return p;
+}
+
+__device__ __forceinline__ int wrap_row(int r, int rows) {
+  if (r < 0) r += rows;
+  if (r >= rows) r -= rows;
+  return r;
+}
+
+// PREFETCH: pull row r+1 before relaxing row r (one row of loads always in flight per wave;
+// +43 VGPRs).  Without it every iteration exposes a full memory round trip.
+template <int MATH, bool NTS, bool PREFETCH>
+__global__ __launch_bounds__(64) void step2_stream(const Step2Args a) {
+  const int lane = threadIdx.x;
+  const int strip = blockIdx.x % a.n_strips;
+  const int band = blockIdx.x / a.n_strips;
+  const int quads_x = a.nx >> 2;
+  const int y0 = band * a.band_rows;
+  const int band_n = min(a.band_rows, a.rows - y0);
+
+  // this lane's quad (may lie outside the grid: halo lanes and the tail of the last strip wrap)
+  const int qx_raw = strip * kStripQuads + lane - 1;
+  int qx = qx_raw % quads_x;
+  if (qx < 0) qx += quads_x;
+  const int x0 = qx << 2;
+  const bool out_lane = (lane >= 1) && (lane <= kStripQuads) && (qx_raw < quads_x);
+  const long ps = a.plane_stride;
+
+  // sliding window of step-t results (registers)
+  float w256[3][4];  // speeds 2,5,6 of row r-2
+  float w013[3][4];  // speeds 0,1,3 of row r-1
+  float n256[3][4];  // speeds 2,5,6 of row r-1 (become w256 after the rotation)
+  uchar4 m_prev = make_uchar4(0, 0, 0, 0);
+  float sum1 = 0.f, sum2 = 0.f;
+
+  RowPull nxt;
+  if constexpr (PREFETCH) nxt = pull_row(a, wrap_row(y0 - 1, a.rows), x0);
+
+  for (int i = 0; i < band_n + 2; i++) {
+    // ---- step t on row r ------------------------------------------------------------------
+    const int r = wrap_row(y0 - 1 + i, a.rows);
+    RowPull p;
+    if constexpr (PREFETCH) {
+      p = nxt;
+      if (i + 1 < band_n + 2) nxt = pull_row(a, wrap_row(y0 + i, a.rows), x0);
+    } else {
+      p = pull_row(a, r, x0);
+    }
+    // +-1 column neighbours of the pulled vectors come from the adjacent lanes.  Lane 0 has no
+    // west lane and lane 63 no east lane: their outermost cells get zeros and produce garbage,
+    // which nothing consumes (those lanes are halo quads; only their inner edge feeds a neighbour).
+    const float e1 = lane_from_west<2>(p.v1.w), e5 = lane_from_west<2>(p.v5.w), e8 = lane_from_west<2>(p.v8.w);
+    const float e3 = lane_from_east<2>(p.v3.x), e6 = lane_from_east<2>(p.v6.x), e7 = lane_from_east<2>(p.v7.x);
+
+    float t[4][kQ] = {
+        {p.v0.x, e1,     p.v2.x, p.v3.y, p.v4.x, e5,     p.v6.y, p.v7.y, e8},
+        {p.v0.y, p.v1.x, p.v2.y, p.v3.z, p.v4.y, p.v5.x, p.v6.z, p.v7.z, p.v8.x},
+        {p.v0.z, p.v1.y, p.v2.z, p.v3.w, p.v4.z, p.v5.y, p.v6.w, p.v7.w, p.v8.y},
+        {p.v0.w, p.v1.z, p.v2.w, e3,     p.v4.w, p.v5.z, e6,     e7,     p.v8.z}};
+    const unsigned char blk[4] = {p.m.x, p.m.y, p.m.z, p.m.w};
+    const bool lid = (r == a.accel_row);
+    const bool own_row = (i >= 1) && (i <= band_n);  // rows y0 .. y0+band_n-1 belong to this band
+    float N[4][kQ];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float speed;
+      relax_cell<MATH>(t[j], blk[j] != 0, lid, a.omega, a.a1, a.a2, N[j], speed);
+      if (own_row && out_lane) sum1 += speed;
+    }
+
+    // ---- step t+1 on row r-1 (needs step-t rows r-2, r-1, r) -------------------------------
+    if (i >= 2) {
+      const int ro = wrap_row(r - 1, a.rows);
+      // neighbours in x from the adjacent lanes: west cell = lane-1's 4th cell, east = lane+1's 1st
+      const float w1 = lane_from_west<2>(w013[1][3]);
+      const float w5 = lane_from_west<2>(w256[1][3]);
+      const float w8 = lane_from_west<2>(N[3][8]);
+      const float x3 = lane_from_east<2>(w013[2][0]);
+      const float x6 = lane_from_east<2>(w256[2][0]);
+      const float x7 = lane_from_east<2>(N[0][7]);
+      float u[4][kQ];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        u[j][0] = w013[0][j];
+        u[j][1] = (j == 0) ? w1 : w013[1][j == 0 ? 0 : j - 1];
+        u[j][2] = w256[0][j];
+        u[j][3] = (j == 3) ? x3 : w013[2][j == 3 ? 3 : j + 1];
+        u[j][4] = N[j][4];
+        u[j][5] = (j == 0) ? w5 : w256[1][j == 0 ? 0 : j - 1];
+        u[j][6] = (j == 3) ? x6 : w256[2][j == 3 ? 3 : j + 1];
+        u[j][7] = (j == 3) ? x7 : N[j == 3 ? 3 : j + 1][7];
+        u[j][8] = (j == 0) ? w8 : N[j == 0 ? 0 : j - 1][8];
+      }
+      const unsigned char pb[4] = {m_prev.x, m_prev.y, m_prev.z, m_prev.w};
+      const bool lid2 = (ro == a.accel_row) && a.accel_after;
+      float R[4][kQ];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float speed;
+        relax_cell<MATH>(u[j], pb[j] != 0, lid2, a.omega, a.a1, a.a2, R[j], speed);
+        if (out_lane) sum2 += speed;
+      }
+      if (out_lane) {
+        float* d_row = a.dst + (long)ro * a.row_pitch + x0;
+#pragma unroll
+        for (int k = 0; k < kQ; k++) store4<NTS>(d_row + k * ps, R[0][k], R[1][k], R[2][k], R[3][k]);
+      }
+    }
+
+    // ---- rotate the window ------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      w256[0][j] = n256[0][j];  w256[1][j] = n256[1][j];  w256[2][j] = n256[2][j];
+      n256[0][j] = N[j][2];     n256[1][j] = N[j][5];     n256[2][j] = N[j][6];
+      w013[0][j] = N[j][0];     w013[1][j] = N[j][1];     w013[2][j] = N[j][3];
+    }
+    m_prev = p.m;
+  }
+
+  sum1 = wave_sum(sum1);
+  sum2 = wave_sum(sum2);
+  if (lane == 0) {
+    a.partials1[blockIdx.x] = sum1;
+    a.partials2[blockIdx.x] = sum2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // fused step, 1 cell per lane: any nx (fallback for widths that are not a multiple of 4)
 // ---------------------------------------------------------------------------------------------
 template <bool EXACT>
@@ -498,13 +705,18 @@ __global__ void pack_halo(const float* lat, long ps, long row_pitch, int pitch, 
   send_north[2 * pitch + x] = lat[6 * ps + top];
 }
 
-// sum the per-workgroup partials of up to gridDim.x steps: block s adds partials[s][0..n_part)
+// sum the per-workgroup partials of up to gridDim.x steps: block s adds partials[s][0..n[s])
 // in a fixed order (double accumulation) -> tot_u[step_base + s].  Deterministic, no atomics.
-__global__ __launch_bounds__(kBlock) void reduce_partials(const float* partials, int n_part,
+constexpr int kPartSlotsMax = 64;
+struct SlotCounts {
+  int n[kPartSlotsMax];  // valid partials in each slot (launch geometries differ between kernels)
+};
+__global__ __launch_bounds__(kBlock) void reduce_partials(const float* partials, SlotCounts counts,
                                                           long slot_stride, double* tot_u,
                                                           int step_base) {
   __shared__ double sh[kBlock];
   const float* p = partials + (long)blockIdx.x * slot_stride;
+  const int n_part = counts.n[blockIdx.x];
   double acc = 0.0;
   for (int i = threadIdx.x; i < n_part; i += kBlock) acc += (double)p[i];
   sh[threadIdx.x] = acc;

@@ -120,7 +120,8 @@ def test_run_in_pieces_equals_one_run(lbm, oracle, datasets):
         for n in (1, 2, 64, 23):
             two.run(n)
         assert np.array_equal(one.cells().view(np.uint32), two.cells().view(np.uint32))
-        assert np.array_equal(one.av_vels(90), two.av_vels(90))
+        # av_vels: same cells, possibly different summation order (one- vs two-step kernels)
+        np.testing.assert_allclose(one.av_vels(90), two.av_vels(90), rtol=1e-6, atol=0)
 
 
 @pytest.mark.parametrize("slabs", [2, 3, 4, 8])
