@@ -70,26 +70,26 @@ struct Slab {
   int device = 0;
   int row_first = 0;  // global row of slab row 0
   int rows = 0;       // owned rows
-  int accel_row = -1; // slab row holding global row ny-2, or -1
-  float* lat[2] = {nullptr, nullptr};
-  unsigned char* mask = nullptr;
+  int accel_row = lbm::kNoRow;  // slab row (may be a halo row: -1 or rows) holding global row ny-2
+  float* lat_alloc[2] = {nullptr, nullptr};  // (rows + 2*kHaloRows) x row_pitch each
+  float* lat[2] = {nullptr, nullptr};        // row 0 of each lattice (= lat_alloc + kHaloRows rows)
+  unsigned char* mask_alloc = nullptr;       // (rows + 2) x pitch: one halo row below and above
+  unsigned char* mask = nullptr;             // row 0 of the mask
   float* partials = nullptr;  // kPartSlots x part_stride
   double* tot_u = nullptr;    // capacity entries: per-step sum of |u| over this slab
   double* scratch = nullptr;  // 2 x kSumBlocks doubles for lattice_sums
-  float* send_south = nullptr;  // 3 x pitch each
-  float* send_north = nullptr;
-  float* recv_south = nullptr;
-  float* recv_north = nullptr;
   hipStream_t compute = nullptr, comm = nullptr;
   hipEvent_t ev_boundary = nullptr, ev_halo = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
   hipEvent_t ev_interior[2] = {nullptr, nullptr};  // interior kernel of step t -> [t & 1]
   hipEvent_t ev_flush = nullptr;                   // partials reduced: their slots may be reused
   ncclComm_t nccl = nullptr;
+  lbm::SlotCounts slot_counts;  // partials written into each buffered slot (launch geometries differ)
   int blocks_main = 0;      // interior rows (or all rows in HALO_SELF)
   int blocks_boundary = 0;  // rows 0 and rows-1 (halo modes)
 };
 
 constexpr int kSumBlocks = 1024;
+constexpr int kHaloRows = 2;  // halo rows kept below and above every slab (two-step kernel needs 2)
 
 }  // namespace
 
@@ -117,7 +117,6 @@ struct lbm_ctx {
   int snake = 0;  // alternate the sweep direction every step (LBM_SNAKE overrides)
   int fuse2 = 0;  // two timesteps per pass (step2_stream) when a single periodic slab allows it
   int band_rows = 64, n_strips = 0, n_bands = 0;  // step2_stream geometry
-  lbm::SlotCounts slot_counts;  // partials written into each buffered slot
 };
 
 namespace {
@@ -139,17 +138,13 @@ int launch_step(lbm_ctx* c, int s, hipStream_t stream, int row_first, int row_st
   a.row_first = row_first;
   a.row_stride = row_stride;
   a.n_rows = n_rows;
-  a.accel_row = accel_epilogue ? sl.accel_row : -1;
+  a.accel_row = accel_epilogue ? sl.accel_row : lbm::kNoRow;
   a.omega = c->p.omega;
   a.a1 = c->p.density * c->p.accel / 9.f;   // SerialCode/d2q9-bgk.c:219
   a.a2 = c->p.density * c->p.accel / 36.f;  // :220
   a.partials = sl.partials + (long)c->slot_fill * c->part_stride + part_offset;
   a.reverse = (c->snake && n_rows > 2) ? (c->cur & 1) : 0;
-  const bool halo = (c->halo != HALO_SELF);
-  a.recv_south = halo ? sl.recv_south : nullptr;
-  a.recv_north = halo ? sl.recv_north : nullptr;
-  a.send_south = halo ? sl.send_south : nullptr;
-  a.send_north = halo ? sl.send_north : nullptr;
+  a.wrap = (c->halo == HALO_SELF) ? 1 : 0;
 
   const bool exact = (c->math_mode == LBM_MATH_EXACT);
   if (c->vec4) {
@@ -173,10 +168,13 @@ int launch_step(lbm_ctx* c, int s, hipStream_t stream, int row_first, int row_st
   return LBM_SUCCESS;
 }
 
-// two timesteps in one pass (single periodic slab): writes the partials of steps t and t+1 into
+// two timesteps in one pass over the rows [row_first, row_end) of slab s, cut into n_bands bands of
+// band_rows rows that start band_pitch rows apart; writes the partials of steps t and t+1 into
 // slots slot_fill and slot_fill+1
-int launch_step2(lbm_ctx* c, bool accel_after) {
-  Slab& sl = c->slab[0];
+int launch_step2(lbm_ctx* c, int s, hipStream_t stream, int row_first, int row_end, int band_rows,
+                 int band_pitch, int band_count, int part_offset, bool accel_after) {
+  Slab& sl = c->slab[s];
+  if (band_count <= 0) return LBM_SUCCESS;
   lbm::Step2Args a;
   a.src = sl.lat[c->cur];
   a.dst = sl.lat[c->cur ^ 1];
@@ -186,71 +184,84 @@ int launch_step2(lbm_ctx* c, bool accel_after) {
   a.pitch = c->pitch;
   a.nx = c->p.nx;
   a.rows = sl.rows;
-  a.band_rows = c->band_rows;
+  a.wrap = (c->halo == HALO_SELF) ? 1 : 0;
+  a.band_rows = band_rows;
+  a.row_first = row_first;
+  a.band_pitch = band_pitch;
+  a.row_end = row_end;
   a.n_strips = c->n_strips;
   a.accel_row = sl.accel_row;
   a.accel_after = accel_after ? 1 : 0;
   a.omega = c->p.omega;
   a.a1 = c->p.density * c->p.accel / 9.f;
   a.a2 = c->p.density * c->p.accel / 36.f;
-  a.partials1 = sl.partials + (long)c->slot_fill * c->part_stride;
+  a.partials1 = sl.partials + (long)c->slot_fill * c->part_stride + part_offset;
   a.partials2 = a.partials1 + c->part_stride;
-  const int waves = c->n_strips * c->n_bands;
+  const int waves = c->n_strips * band_count;
   typedef void (*fn)(const lbm::Step2Args);
   static const fn table[2][2][2] = {
       {{lbm::step2_stream<0, false, false>, lbm::step2_stream<0, false, true>},
        {lbm::step2_stream<0, true, false>, lbm::step2_stream<0, true, true>}},
       {{lbm::step2_stream<1, false, false>, lbm::step2_stream<1, false, true>},
        {lbm::step2_stream<1, true, false>, lbm::step2_stream<1, true, true>}}};
-  static const int prefetch = env_int("LBM_PREFETCH", 1) ? 1 : 0;
+  static const int prefetch = env_int("LBM_PREFETCH", 0) ? 1 : 0;
   hipLaunchKernelGGL(table[c->math_mode == LBM_MATH_EXACT ? 0 : 1][c->nts][prefetch], dim3(waves), dim3(64), 0,
-                     sl.compute, a);
+                     stream, a);
   HIP_TRY(LBM_FAILURE, hipGetLastError());
-  c->slot_counts.n[c->slot_fill] = waves;
-  c->slot_counts.n[c->slot_fill + 1] = waves;
   return LBM_SUCCESS;
 }
 
+// Two-step kernel across slabs: an output row y reads source rows y-2 .. y+2, so only rows 0,1 and
+// rows-2, rows-1 touch halo rows.  They form two 2-row bands (short sweeps: low latency on the comm
+// stream); rows [2, rows-2) are the interior region, cut into bands of band_rows.
 int blocks_for_rows(const lbm_ctx* c, int n_rows) {
   if (n_rows <= 0) return 0;
   return c->vec4 ? ceil_div((long)(c->p.nx / 4) * n_rows, lbm::kBlock)
                  : ceil_div((long)c->p.nx * n_rows, lbm::kBlock);
 }
 
-// One halo exchange, enqueued on the comm streams: every slab's packed send rows travel to its
-// ring neighbours' recv rows.  north neighbour of slab s = s+1 (periodic), south = s-1; across
-// processes the ring runs over ranks (MPI/d2q9-bgk.c:210-211).
-// Precondition (stream order): the kernel that filled the send rows was enqueued on the same comm
-// stream (boundary kernel), or the comm stream already waits for it (first exchange of a run).
-int exchange_halos(lbm_ctx* c) {
-  const long n = 3L * c->pitch;
+// One halo exchange, enqueued on the comm streams: the `depth` boundary rows at each end of every
+// slab's CURRENT lattice travel, whole (all 9 speeds, as MPI_Waitall/d2q9-bgk.c:225-230 ships
+// them), into the halo rows of its ring neighbours' current lattices -- zero copy on both sides,
+// because halo rows and boundary rows are contiguous in the row-interleaved layout.
+//   my rows [rows-depth, rows)  ->  north neighbour's rows [-depth, 0)
+//   my rows [0, depth)          ->  south neighbour's rows [rows_s, rows_s + depth)
+// north neighbour of slab s = s+1 (periodic), south = s-1; across processes the ring runs over
+// ranks (MPI/d2q9-bgk.c:210-211).  Precondition (stream order): the kernels that wrote the
+// boundary rows are ordered before this on the comm stream.
+int exchange_halos(lbm_ctx* c, int depth) {
+  const long n = (long)depth * c->row_pitch;
   if (c->halo == HALO_RCCL) {
     NCCL_TRY(LBM_FAILURE, ncclGroupStart());
     for (int s = 0; s < c->n_slabs; s++) {
       Slab& sl = c->slab[s];
+      float* lat = sl.lat[c->cur];
       int me, parts;
       if (c->ranked) { me = c->rank; parts = c->world; } else { me = s; parts = c->n_slabs; }
       const int north = (me + 1) % parts, south = (me - 1 + parts) % parts;
       // order matters when north == south (2 parts): first send pairs with the peer's first recv
-      NCCL_TRY(LBM_FAILURE, ncclSend(sl.send_north, n, ncclFloat, north, sl.nccl, sl.comm));
-      NCCL_TRY(LBM_FAILURE, ncclSend(sl.send_south, n, ncclFloat, south, sl.nccl, sl.comm));
-      NCCL_TRY(LBM_FAILURE, ncclRecv(sl.recv_south, n, ncclFloat, south, sl.nccl, sl.comm));
-      NCCL_TRY(LBM_FAILURE, ncclRecv(sl.recv_north, n, ncclFloat, north, sl.nccl, sl.comm));
+      NCCL_TRY(LBM_FAILURE, ncclSend(lat + (long)(sl.rows - depth) * c->row_pitch, n, ncclFloat, north, sl.nccl, sl.comm));
+      NCCL_TRY(LBM_FAILURE, ncclSend(lat, n, ncclFloat, south, sl.nccl, sl.comm));
+      NCCL_TRY(LBM_FAILURE, ncclRecv(lat - n, n, ncclFloat, south, sl.nccl, sl.comm));
+      NCCL_TRY(LBM_FAILURE, ncclRecv(lat + (long)sl.rows * c->row_pitch, n, ncclFloat, north, sl.nccl, sl.comm));
     }
     NCCL_TRY(LBM_FAILURE, ncclGroupEnd());
   } else if (c->halo == HALO_MEMCPY) {
-    // push model inside one process: slab s copies its send rows into its neighbours' recv rows
-    // once the neighbours' boundary kernels have consumed the previous contents (ev_boundary);
-    // the neighbours' next boundary kernels wait for ev_halo of the pushing slabs.
+    // push model inside one process: slab s copies its boundary rows into its neighbours' halo rows
+    // once the neighbours' boundary kernels have finished with the previous contents
+    // (ev_boundary); the neighbours' next boundary kernels wait for ev_halo of the pushing slabs.
     for (int s = 0; s < c->n_slabs; s++) {
       Slab& sl = c->slab[s];
       const int north = (s + 1) % c->n_slabs, south = (s - 1 + c->n_slabs) % c->n_slabs;
+      float* lat = sl.lat[c->cur];
+      Slab& sn = c->slab[north];
+      Slab& ss = c->slab[south];
       HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
-      HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, c->slab[north].ev_boundary, 0));
-      HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, c->slab[south].ev_boundary, 0));
-      HIP_TRY(LBM_FAILURE, hipMemcpyAsync(c->slab[north].recv_south, sl.send_north, n * sizeof(float),
-                                          hipMemcpyDefault, sl.comm));
-      HIP_TRY(LBM_FAILURE, hipMemcpyAsync(c->slab[south].recv_north, sl.send_south, n * sizeof(float),
+      HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sn.ev_boundary, 0));
+      HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, ss.ev_boundary, 0));
+      HIP_TRY(LBM_FAILURE, hipMemcpyAsync(sn.lat[c->cur] - n, lat + (long)(sl.rows - depth) * c->row_pitch,
+                                          n * sizeof(float), hipMemcpyDefault, sl.comm));
+      HIP_TRY(LBM_FAILURE, hipMemcpyAsync(ss.lat[c->cur] + (long)ss.rows * c->row_pitch, lat, n * sizeof(float),
                                           hipMemcpyDefault, sl.comm));
       HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_halo, sl.comm));
     }
@@ -267,7 +278,7 @@ int flush_partials(lbm_ctx* c, int step_base) {
     // the boundary rows' partials are written on the comm stream
     if (c->halo != HALO_SELF) HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, sl.ev_boundary, 0));
     hipLaunchKernelGGL(lbm::reduce_partials, dim3(c->slot_fill), dim3(lbm::kBlock), 0, sl.compute,
-                       sl.partials, c->slot_counts, c->part_stride, sl.tot_u, step_base);
+                       sl.partials, sl.slot_counts, c->part_stride, sl.tot_u, step_base);
     HIP_TRY(LBM_FAILURE, hipGetLastError());
     if (c->halo != HALO_SELF) {
       // the next boundary kernels (comm stream) reuse the partial slots just read
@@ -306,26 +317,24 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
   for (int s = 0; s < c->n_slabs; s++) {
     Slab& sl = c->slab[s];
     HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
-    if (sl.accel_row >= 0) {
+    if (sl.accel_row >= 0 && sl.accel_row < sl.rows) {
       hipLaunchKernelGGL(lbm::accelerate_row, dim3(ceil_div(c->p.nx, 256)), dim3(256), 0, sl.compute,
                          sl.lat[c->cur], sl.mask, c->plane_stride, c->row_pitch, c->pitch, c->p.nx,
                          sl.accel_row, a1, a2);
       HIP_TRY(LBM_FAILURE, hipGetLastError());
     }
     if (halo) {
-      hipLaunchKernelGGL(lbm::pack_halo, dim3(ceil_div(c->p.nx, 256)), dim3(256), 0, sl.compute,
-                         sl.lat[c->cur], c->plane_stride, c->row_pitch, c->pitch, c->p.nx, sl.rows,
-                         sl.send_south, sl.send_north);
-      HIP_TRY(LBM_FAILURE, hipGetLastError());
-      // "I(-1)": lattice and packed rows are ready; also orders the comm stream after everything
-      // a previous lbm_run left on the compute stream
+      // "I(-1)": the lattice is ready; also orders the comm stream after everything a previous
+      // lbm_run left on the compute stream
       HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_interior[1], sl.compute));
       HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sl.ev_interior[1], 0));
       // boundary event in a defined state for the first memcpy exchange
       HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_boundary, sl.comm));
     }
   }
-  if (halo && exchange_halos(c) != LBM_SUCCESS) return LBM_FAILURE;
+  // halo depth: the two-step kernel reads two rows beyond the slab
+  const int depth = c->fuse2 ? 2 : 1;
+  if (halo && exchange_halos(c, depth) != LBM_SUCCESS) return LBM_FAILURE;
 
   if (kernel_ms)
     for (int s = 0; s < c->n_slabs; s++) {
@@ -333,54 +342,65 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
       HIP_TRY(LBM_FAILURE, hipEventRecord(c->slab[s].ev_t0, c->slab[s].compute));
     }
 
+  // macro steps: two timesteps per pass where enabled and at least two remain, else one
   int flushed_upto = c->steps_done;
-  for (int t = 0; t < n_steps; t++) {
-    // two steps per pass where possible (single periodic slab, vector kernel)
-    if (c->fuse2 && !halo && t + 1 < n_steps) {
-      HIP_TRY(LBM_FAILURE, hipSetDevice(c->slab[0].device));
-      if (launch_step2(c, /*accel_after=*/t + 2 < n_steps) != LBM_SUCCESS) return LBM_FAILURE;
-      c->cur ^= 1;
-      c->slot_fill += 2;
-      t += 1;
-      if (c->slot_fill >= kPartSlots - 1 || t == n_steps - 1) {
-        if (flush_partials(c, flushed_upto) != LBM_SUCCESS) return LBM_FAILURE;
-        flushed_upto += c->slot_fill;
-        c->slot_fill = 0;
-      }
-      continue;
-    }
-    const bool last = (t == n_steps - 1);
-    // interior rows (or the whole slab) on the compute streams
+  int m = 0;  // macro step counter (event parity)
+  for (int t = 0; t < n_steps; m++) {
+    const bool two = c->fuse2 && (t + 1 < n_steps);
+    const int adv = two ? 2 : 1;
+    const bool last = (t + adv == n_steps);
     for (int s = 0; s < c->n_slabs; s++) {
       Slab& sl = c->slab[s];
       HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
-      if (!halo) {
-        if (launch_step(c, s, sl.compute, 0, 1, sl.rows, 0, !last) != LBM_SUCCESS) return LBM_FAILURE;
+      if (halo && m > 0) HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, sl.ev_boundary, 0));  // B(m-1)
+      if (two) {
+        // whole slab when periodic; otherwise the rows that touch no halo row
+        const int r0 = halo ? 2 : 0, r1 = halo ? sl.rows - 2 : sl.rows;
+        if (launch_step2(c, s, sl.compute, r0, r1, c->band_rows, c->band_rows, ceil_div(r1 - r0, c->band_rows), 0,
+                         !last) != LBM_SUCCESS)
+          return LBM_FAILURE;
       } else {
-        if (t > 0) HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, sl.ev_boundary, 0));  // B(t-1)
-        if (launch_step(c, s, sl.compute, 1, 1, sl.rows - 2, 0, !last) != LBM_SUCCESS) return LBM_FAILURE;
-        HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_interior[t & 1], sl.compute));
+        if (!halo) {
+          if (launch_step(c, s, sl.compute, 0, 1, sl.rows, 0, !last) != LBM_SUCCESS) return LBM_FAILURE;
+        } else {
+          if (launch_step(c, s, sl.compute, 1, 1, sl.rows - 2, 0, !last) != LBM_SUCCESS) return LBM_FAILURE;
+        }
       }
+      if (halo) HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_interior[m & 1], sl.compute));
     }
     if (halo) {
-      // boundary rows 0 and rows-1 on the comm streams, behind the exchange X(t)
+      // boundary rows / bands on the comm streams, behind the exchange X(m)
       for (int s = 0; s < c->n_slabs; s++) {
         Slab& sl = c->slab[s];
         HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
-        HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sl.ev_interior[(t + 1) & 1], 0));  // I(t-1)
+        HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sl.ev_interior[(m + 1) & 1], 0));  // I(m-1)
         if (c->halo == HALO_MEMCPY) {
           const int north = (s + 1) % c->n_slabs, south = (s - 1 + c->n_slabs) % c->n_slabs;
           HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, c->slab[north].ev_halo, 0));
           HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, c->slab[south].ev_halo, 0));
         }
-        if (launch_step(c, s, sl.comm, 0, sl.rows - 1, 2, sl.blocks_main, !last) != LBM_SUCCESS) return LBM_FAILURE;
+        if (two) {
+          // rows 0,1 and rows-2,rows-1 as two 2-row bands in one launch
+          const int off = c->n_strips * ceil_div(sl.rows - 4, c->band_rows);
+          if (launch_step2(c, s, sl.comm, 0, sl.rows, 2, sl.rows - 2, 2, off, !last) != LBM_SUCCESS) return LBM_FAILURE;
+        } else {
+          if (launch_step(c, s, sl.comm, 0, sl.rows - 1, 2, sl.blocks_main, !last) != LBM_SUCCESS) return LBM_FAILURE;
+        }
         HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_boundary, sl.comm));
       }
-      if (!last && exchange_halos(c) != LBM_SUCCESS) return LBM_FAILURE;
     }
-    c->slot_counts.n[c->slot_fill] = c->slab[0].blocks_main + c->slab[0].blocks_boundary;
+    // bookkeeping of the partial slots written by this macro step
+    for (int s = 0; s < c->n_slabs; s++) {
+      Slab& sl = c->slab[s];
+      const int fused_waves = halo ? c->n_strips * (ceil_div(sl.rows - 4, c->band_rows) + 2)
+                                   : c->n_strips * ceil_div(sl.rows, c->band_rows);
+      const int n_part = two ? fused_waves : sl.blocks_main + sl.blocks_boundary;
+      for (int k = 0; k < adv; k++) sl.slot_counts.n[c->slot_fill + k] = n_part;
+    }
     c->cur ^= 1;
-    c->slot_fill++;
+    c->slot_fill += adv;
+    t += adv;
+    if (halo && !last && exchange_halos(c, depth) != LBM_SUCCESS) return LBM_FAILURE;
     if (c->slot_fill >= kPartSlots - 1 || last) {
       if (flush_partials(c, flushed_upto) != LBM_SUCCESS) return LBM_FAILURE;
       flushed_upto += c->slot_fill;
@@ -413,15 +433,11 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
 void free_slab(Slab& sl) {
   if (hipSetDevice(sl.device) != hipSuccess) return;
   if (sl.nccl) ncclCommDestroy(sl.nccl);
-  for (int i = 0; i < 2; i++) if (sl.lat[i]) (void)hipFree(sl.lat[i]);
-  if (sl.mask) (void)hipFree(sl.mask);
+  for (int i = 0; i < 2; i++) if (sl.lat_alloc[i]) (void)hipFree(sl.lat_alloc[i]);
+  if (sl.mask_alloc) (void)hipFree(sl.mask_alloc);
   if (sl.partials) (void)hipFree(sl.partials);
   if (sl.tot_u) (void)hipFree(sl.tot_u);
   if (sl.scratch) (void)hipFree(sl.scratch);
-  if (sl.send_south) (void)hipFree(sl.send_south);
-  if (sl.send_north) (void)hipFree(sl.send_north);
-  if (sl.recv_south) (void)hipFree(sl.recv_south);
-  if (sl.recv_north) (void)hipFree(sl.recv_north);
   if (sl.ev_boundary) (void)hipEventDestroy(sl.ev_boundary);
   if (sl.ev_halo) (void)hipEventDestroy(sl.ev_halo);
   for (int i = 0; i < 2; i++) if (sl.ev_interior[i]) (void)hipEventDestroy(sl.ev_interior[i]);
@@ -452,34 +468,37 @@ int build_slab(lbm_ctx* c, int s, const int* obstacles, const float* cells_aos) 
   HIP_TRY(LBM_FAILURE, hipEventCreate(&sl.ev_t0));
   HIP_TRY(LBM_FAILURE, hipEventCreate(&sl.ev_t1));
 
-  const long cells = (long)sl.rows * c->pitch;  // mask entries
-  const size_t lat_bytes = (size_t)sl.rows * c->row_pitch * sizeof(float);
-  for (int i = 0; i < 2; i++) HIP_TRY(LBM_FAILURE, hipMalloc(&sl.lat[i], lat_bytes));
-  HIP_TRY(LBM_FAILURE, hipMalloc(&sl.mask, (size_t)cells));
+  // lattices with kHaloRows halo rows below and above the owned rows (zeroed: pitch padding and
+  // unused halo rows stay finite); lat[] points at owned row 0
+  const size_t lat_bytes = (size_t)(sl.rows + 2 * kHaloRows) * c->row_pitch * sizeof(float);
+  for (int i = 0; i < 2; i++) {
+    HIP_TRY(LBM_FAILURE, hipMalloc(&sl.lat_alloc[i], lat_bytes));
+    HIP_TRY(LBM_FAILURE, hipMemsetAsync(sl.lat_alloc[i], 0, lat_bytes, sl.compute));
+    sl.lat[i] = sl.lat_alloc[i] + (size_t)kHaloRows * c->row_pitch;
+  }
   HIP_TRY(LBM_FAILURE, hipMalloc(&sl.partials, (size_t)kPartSlots * c->part_stride * sizeof(float)));
   HIP_TRY(LBM_FAILURE, hipMemsetAsync(sl.partials, 0, (size_t)kPartSlots * c->part_stride * sizeof(float), sl.compute));
   HIP_TRY(LBM_FAILURE, hipMalloc(&sl.tot_u, (size_t)(c->capacity > 0 ? c->capacity : 1) * sizeof(double)));
   HIP_TRY(LBM_FAILURE, hipMemsetAsync(sl.tot_u, 0, (size_t)(c->capacity > 0 ? c->capacity : 1) * sizeof(double), sl.compute));
   HIP_TRY(LBM_FAILURE, hipMalloc(&sl.scratch, 2 * kSumBlocks * sizeof(double)));
-  const size_t halo_bytes = 3 * (size_t)c->pitch * sizeof(float);
-  HIP_TRY(LBM_FAILURE, hipMalloc(&sl.send_south, halo_bytes));
-  HIP_TRY(LBM_FAILURE, hipMalloc(&sl.send_north, halo_bytes));
-  HIP_TRY(LBM_FAILURE, hipMalloc(&sl.recv_south, halo_bytes));
-  HIP_TRY(LBM_FAILURE, hipMalloc(&sl.recv_north, halo_bytes));
 
-  // obstacle mask: int (reference host type, SerialCode/d2q9-bgk.c:541) -> uint8 rows x pitch
+  // obstacle mask: int (reference host type, SerialCode/d2q9-bgk.c:541) -> uint8 (rows+2) x pitch,
+  // with the (periodic) neighbour rows -1 and `rows` so that a slab can relax its halo rows
   {
-    std::vector<unsigned char> m((size_t)cells, 0);
-    for (int r = 0; r < sl.rows; r++) {
-      const int* src = obstacles + (size_t)(sl.row_first + r) * p.nx;
-      unsigned char* dst = m.data() + (size_t)r * c->pitch;
+    const long mask_cells = (long)(sl.rows + 2) * c->pitch;
+    std::vector<unsigned char> m((size_t)mask_cells, 0);
+    for (int r = -1; r <= sl.rows; r++) {
+      const int g = ((sl.row_first + r) % p.ny + p.ny) % p.ny;
+      const int* src = obstacles + (size_t)g * p.nx;
+      unsigned char* dst = m.data() + (size_t)(r + 1) * c->pitch;
       for (int x = 0; x < p.nx; x++) dst[x] = src[x] ? 1 : 0;
     }
-    HIP_TRY(LBM_FAILURE, hipMemcpy(sl.mask, m.data(), (size_t)cells, hipMemcpyHostToDevice));
+    HIP_TRY(LBM_FAILURE, hipMalloc(&sl.mask_alloc, (size_t)mask_cells));
+    HIP_TRY(LBM_FAILURE, hipMemcpy(sl.mask_alloc, m.data(), (size_t)mask_cells, hipMemcpyHostToDevice));
+    sl.mask = sl.mask_alloc + c->pitch;
   }
 
-  // lattice: zero both (pitch padding stays finite), then equilibrium or the caller's cells
-  for (int i = 0; i < 2; i++) HIP_TRY(LBM_FAILURE, hipMemsetAsync(sl.lat[i], 0, lat_bytes, sl.compute));
+  // lattice: equilibrium or the caller's cells
   if (!cells_aos) {
     const float r0 = p.density * 4.f / 9.f;  // SerialCode/d2q9-bgk.c:546-548
     const float r1 = p.density / 9.f;
@@ -576,7 +595,15 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
     sl.row_first = c->row_first + first;
     sl.rows = count;
     const int lid = params->ny - 2;  // SerialCode/d2q9-bgk.c:223
-    sl.accel_row = (lid >= sl.row_first && lid < sl.row_first + sl.rows) ? lid - sl.row_first : -1;
+    // slab-local index of the lid row; with several slabs it may be one of MY halo rows (-1 or
+    // rows), which the two-step kernel relaxes redundantly and must accelerate like its owner does
+    sl.accel_row = lbm::kNoRow;
+    for (int shift = -1; shift <= 1; shift++) {
+      const int local = lid + shift * params->ny - sl.row_first;
+      const bool owned = (local >= 0 && local < sl.rows);
+      const bool in_halo = (c->halo != HALO_SELF) && (local == -1 || local == sl.rows);
+      if (owned || in_halo) sl.accel_row = local;
+    }
     if (c->halo == HALO_SELF) {
       sl.blocks_main = blocks_for_rows(c, sl.rows);
       sl.blocks_boundary = 0;
@@ -596,8 +623,13 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
   if (c->band_rows < 1) c->band_rows = 1;
   c->n_strips = ceil_div(params->nx / 4 > 0 ? params->nx / 4 : 1, lbm::kStripQuads);
   c->n_bands = ceil_div(c->row_count, c->band_rows);
-  c->fuse2 = (c->halo == HALO_SELF && c->vec4 && env_int("LBM_FUSE2", 0)) ? 1 : 0;
-  if (c->fuse2 && c->n_strips * c->n_bands > max_blocks) max_blocks = c->n_strips * c->n_bands;
+  c->fuse2 = (c->vec4 && env_int("LBM_FUSE2", 0)) ? 1 : 0;
+  for (int s = 0; s < n_slabs; s++) {
+    // across slabs the two-step kernel needs band_rows >= 2 and slabs of at least 4 rows
+    if (c->halo != HALO_SELF && (c->slab[s].rows < 4 || c->band_rows < 2)) c->fuse2 = 0;
+    const int waves = c->n_strips * (ceil_div(c->slab[s].rows, c->band_rows) + 2);
+    if (c->fuse2 && waves > max_blocks) max_blocks = waves;
+  }
   c->part_stride = round_up(max_blocks, 64);
 
   for (int s = 0; s < n_slabs; s++)

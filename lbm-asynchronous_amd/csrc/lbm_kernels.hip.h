@@ -29,6 +29,7 @@ namespace lbm {
 
 constexpr int kBlock = 256;  // 4 waves of 64
 constexpr int kQ = 9;
+constexpr int kNoRow = -1000000;  // "no such row in this slab"
 
 // 1/3 rounded to fp32, and the two constant divisors of the equilibrium, folded in fp32
 // exactly as the reference's "2.f * c_sq" and "2.f * c_sq * c_sq" (SerialCode/d2q9-bgk.c:308,367-370)
@@ -51,16 +52,13 @@ struct StepArgs {
   int row_first;              // first slab row this launch advances
   int row_stride;             // distance between the rows this launch advances (1 = contiguous)
   int n_rows;                 // number of rows this launch advances
-  int accel_row;              // slab row that receives next step's acceleration, or -1
+  int accel_row;              // slab row that receives next step's acceleration, or kNoRow
   float omega;
   float a1, a2;               // density*accel/9, density*accel/36 (SerialCode/d2q9-bgk.c:219-220)
   float* partials;            // one fp32 partial sum of |u| per workgroup of this launch
   int reverse;                // 1: workgroup b handles tile (n_tiles-1-b): rows are swept top-down
-  // packed halo rows (NULL in the single-slab periodic case):
-  const float* recv_south;    // 3 x pitch: planes 2,5,6 of the row below slab row 0
-  const float* recv_north;    // 3 x pitch: planes 4,7,8 of the row above slab row rows-1
-  float* send_south;          // 3 x pitch: planes 4,7,8 of slab row 0 after this step
-  float* send_north;          // 3 x pitch: planes 2,5,6 of slab row rows-1 after this step
+  int wrap;                   // 1: the slab is the whole grid, rows wrap periodically;
+                              // 0: rows -1 and `rows` are halo rows stored around the slab
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -300,22 +298,14 @@ __global__ __launch_bounds__(BLOCK) void step_vec4(const StepArgs a) {
     const int xe = (x0 + 4 == a.nx) ? 0 : x0 + 4;
 
     const float* c_row = a.src + (long)row * a.row_pitch;  // plane 0, this row
-    // row below (speeds 2,5,6 arrive from it) and above (4,7,8), :257,259
-    const float *s2, *s5, *s6, *n4, *n7, *n8;
-    if (row == 0 && a.recv_south) {
-      s2 = a.recv_south;  s5 = s2 + a.pitch;  s6 = s5 + a.pitch;
-    } else {
-      const int rs = (row == 0) ? a.rows - 1 : row - 1;
-      const float* b = a.src + (long)rs * a.row_pitch;
-      s2 = b + 2 * ps;  s5 = b + 5 * ps;  s6 = b + 6 * ps;
-    }
-    if (row == a.rows - 1 && a.recv_north) {
-      n4 = a.recv_north;  n7 = n4 + a.pitch;  n8 = n7 + a.pitch;
-    } else {
-      const int rn = (row == a.rows - 1) ? 0 : row + 1;
-      const float* b = a.src + (long)rn * a.row_pitch;
-      n4 = b + 4 * ps;  n7 = b + 7 * ps;  n8 = b + 8 * ps;
-    }
+    // row below (speeds 2,5,6 arrive from it) and above (4,7,8), :257,259.  In a multi-slab run the
+    // slab is surrounded by halo rows (-1 and `rows`) that hold the neighbours' boundary rows.
+    const int rs = (row == 0 && a.wrap) ? a.rows - 1 : row - 1;
+    const int rn = (row == a.rows - 1 && a.wrap) ? 0 : row + 1;
+    const float* sb = a.src + (long)rs * a.row_pitch;
+    const float* nb = a.src + (long)rn * a.row_pitch;
+    const float *s2 = sb + 2 * ps, *s5 = sb + 5 * ps, *s6 = sb + 6 * ps;
+    const float *n4 = nb + 4 * ps, *n7 = nb + 7 * ps, *n8 = nb + 8 * ps;
 
     // 9 aligned 16-byte loads
     const float4 v0 = *reinterpret_cast<const float4*>(c_row + x0);
@@ -389,19 +379,6 @@ __global__ __launch_bounds__(BLOCK) void step_vec4(const StepArgs a) {
 #pragma unroll
     for (int k = 0; k < kQ; k++) store4<NTS>(d_row + k * ps, r[0][k], r[1][k], r[2][k], r[3][k]);
 
-    // packed halo rows for the neighbours' next step
-    if (a.send_south && row == 0) {
-      float* o = a.send_south + x0;
-      *reinterpret_cast<float4*>(o) = make_float4(r[0][4], r[1][4], r[2][4], r[3][4]);
-      *reinterpret_cast<float4*>(o + a.pitch) = make_float4(r[0][7], r[1][7], r[2][7], r[3][7]);
-      *reinterpret_cast<float4*>(o + 2 * a.pitch) = make_float4(r[0][8], r[1][8], r[2][8], r[3][8]);
-    }
-    if (a.send_north && row == a.rows - 1) {
-      float* o = a.send_north + x0;
-      *reinterpret_cast<float4*>(o) = make_float4(r[0][2], r[1][2], r[2][2], r[3][2]);
-      *reinterpret_cast<float4*>(o + a.pitch) = make_float4(r[0][5], r[1][5], r[2][5], r[3][5]);
-      *reinterpret_cast<float4*>(o + 2 * a.pitch) = make_float4(r[0][6], r[1][6], r[2][6], r[3][6]);
-    }
   }
 
   const float total = block_sum<BLOCK>(my_sum);
@@ -439,8 +416,12 @@ struct Step2Args {
   long row_pitch;
   int pitch;
   int nx;
-  int rows;        // grid rows (periodic)
-  int band_rows;   // output rows per wave
+  int rows;        // rows owned by the slab
+  int wrap;        // 1: rows wrap periodically (single slab); 0: two halo rows surround the slab
+  int band_rows;   // output rows per wave (band height)
+  int row_first;   // band b of this launch starts at row_first + b*band_pitch ...
+  int band_pitch;  // (= band_rows for a contiguous region)
+  int row_end;     // ... and ends before row_end
   int n_strips;    // waves across x
   int accel_row;
   int accel_after;
@@ -472,8 +453,8 @@ struct RowPull {
 
 __device__ __forceinline__ RowPull pull_row(const Step2Args& a, int r, int x0) {
   const long ps = a.plane_stride;
-  const int rs = (r == 0) ? a.rows - 1 : r - 1;
-  const int rn = (r == a.rows - 1) ? 0 : r + 1;
+  const int rs = (r == 0 && a.wrap) ? a.rows - 1 : r - 1;
+  const int rn = (r == a.rows - 1 && a.wrap) ? 0 : r + 1;
   const float* c_row = a.src + (long)r * a.row_pitch;
   const float* sb = a.src + (long)rs * a.row_pitch;
   const float* nb = a.src + (long)rn * a.row_pitch;
@@ -491,9 +472,12 @@ __device__ __forceinline__ RowPull pull_row(const Step2Args& a, int r, int x0) {
   return p;
 }
 
-__device__ __forceinline__ int wrap_row(int r, int rows) {
-  if (r < 0) r += rows;
-  if (r >= rows) r -= rows;
+// periodic single slab: fold the row index; multi-slab: rows -2..rows+1 exist as halo rows
+__device__ __forceinline__ int wrap_row(int r, int rows, int wrap) {
+  if (wrap) {
+    if (r < 0) r += rows;
+    if (r >= rows) r -= rows;
+  }
   return r;
 }
 
@@ -503,10 +487,9 @@ template <int MATH, bool NTS, bool PREFETCH>
 __global__ __launch_bounds__(64) void step2_stream(const Step2Args a) {
   const int lane = threadIdx.x;
   const int strip = blockIdx.x % a.n_strips;
-  const int band = blockIdx.x / a.n_strips;
   const int quads_x = a.nx >> 2;
-  const int y0 = band * a.band_rows;
-  const int band_n = min(a.band_rows, a.rows - y0);
+  const int y0 = a.row_first + (int)(blockIdx.x / a.n_strips) * a.band_pitch;
+  const int band_n = min(a.band_rows, a.row_end - y0);
 
   // this lane's quad (may lie outside the grid: halo lanes and the tail of the last strip wrap)
   const int qx_raw = strip * kStripQuads + lane - 1;
@@ -524,15 +507,15 @@ __global__ __launch_bounds__(64) void step2_stream(const Step2Args a) {
   float sum1 = 0.f, sum2 = 0.f;
 
   RowPull nxt;
-  if constexpr (PREFETCH) nxt = pull_row(a, wrap_row(y0 - 1, a.rows), x0);
+  if constexpr (PREFETCH) nxt = pull_row(a, wrap_row(y0 - 1, a.rows, a.wrap), x0);
 
   for (int i = 0; i < band_n + 2; i++) {
     // ---- step t on row r ------------------------------------------------------------------
-    const int r = wrap_row(y0 - 1 + i, a.rows);
+    const int r = wrap_row(y0 - 1 + i, a.rows, a.wrap);
     RowPull p;
     if constexpr (PREFETCH) {
       p = nxt;
-      if (i + 1 < band_n + 2) nxt = pull_row(a, wrap_row(y0 + i, a.rows), x0);
+      if (i + 1 < band_n + 2) nxt = pull_row(a, wrap_row(y0 + i, a.rows, a.wrap), x0);
     } else {
       p = pull_row(a, r, x0);
     }
@@ -560,7 +543,7 @@ __global__ __launch_bounds__(64) void step2_stream(const Step2Args a) {
 
     // ---- step t+1 on row r-1 (needs step-t rows r-2, r-1, r) -------------------------------
     if (i >= 2) {
-      const int ro = wrap_row(r - 1, a.rows);
+      const int ro = wrap_row(r - 1, a.rows, a.wrap);
       // neighbours in x from the adjacent lanes: west cell = lane-1's 4th cell, east = lane+1's 1st
       const float w1 = lane_from_west<2>(w013[1][3]);
       const float w5 = lane_from_west<2>(w256[1][3]);
@@ -631,21 +614,12 @@ __global__ __launch_bounds__(kBlock) void step_scalar(const StepArgs a) {
     const int xe = (x + 1 == a.nx) ? 0 : x + 1;
     const long ps = a.plane_stride;
     const float* c_row = a.src + (long)row * a.row_pitch;
-    const float *s2, *s5, *s6, *n4, *n7, *n8;
-    if (row == 0 && a.recv_south) {
-      s2 = a.recv_south;  s5 = s2 + a.pitch;  s6 = s5 + a.pitch;
-    } else {
-      const int rs = (row == 0) ? a.rows - 1 : row - 1;
-      const float* b = a.src + (long)rs * a.row_pitch;
-      s2 = b + 2 * ps;  s5 = b + 5 * ps;  s6 = b + 6 * ps;
-    }
-    if (row == a.rows - 1 && a.recv_north) {
-      n4 = a.recv_north;  n7 = n4 + a.pitch;  n8 = n7 + a.pitch;
-    } else {
-      const int rn = (row == a.rows - 1) ? 0 : row + 1;
-      const float* b = a.src + (long)rn * a.row_pitch;
-      n4 = b + 4 * ps;  n7 = b + 7 * ps;  n8 = b + 8 * ps;
-    }
+    const int rs = (row == 0 && a.wrap) ? a.rows - 1 : row - 1;
+    const int rn = (row == a.rows - 1 && a.wrap) ? 0 : row + 1;
+    const float* sb = a.src + (long)rs * a.row_pitch;
+    const float* nb = a.src + (long)rn * a.row_pitch;
+    const float *s2 = sb + 2 * ps, *s5 = sb + 5 * ps, *s6 = sb + 6 * ps;
+    const float *n4 = nb + 4 * ps, *n7 = nb + 7 * ps, *n8 = nb + 8 * ps;
     float t[kQ] = {c_row[x], c_row[1 * ps + xw], s2[x], c_row[3 * ps + xe], n4[x],
                    s5[xw],   s6[xe],             n7[xe], n8[xw]};
     float r[kQ];
@@ -660,12 +634,6 @@ __global__ __launch_bounds__(kBlock) void step_scalar(const StepArgs a) {
     float* d = a.dst + (long)row * a.row_pitch + x;
 #pragma unroll
     for (int k = 0; k < kQ; k++) d[k * ps] = r[k];
-    if (a.send_south && row == 0) {
-      a.send_south[x] = r[4];  a.send_south[a.pitch + x] = r[7];  a.send_south[2 * a.pitch + x] = r[8];
-    }
-    if (a.send_north && row == a.rows - 1) {
-      a.send_north[x] = r[2];  a.send_north[a.pitch + x] = r[5];  a.send_north[2 * a.pitch + x] = r[6];
-    }
   }
   const float total = block_sum(my_sum);
   if (threadIdx.x == 0) a.partials[blockIdx.x] = total;
@@ -689,20 +657,6 @@ __global__ void accelerate_row(float* lat, const unsigned char* mask, long ps, l
   accelerate(f, a1, a2);
   lat[1 * ps + c] = f[1];  lat[3 * ps + c] = f[3];  lat[5 * ps + c] = f[5];
   lat[6 * ps + c] = f[6];  lat[7 * ps + c] = f[7];  lat[8 * ps + c] = f[8];
-}
-
-// fill the packed send rows from the current lattice (before the first halo exchange of a run)
-__global__ void pack_halo(const float* lat, long ps, long row_pitch, int pitch, int nx, int rows,
-                          float* send_south, float* send_north) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x >= nx) return;
-  const long top = (long)(rows - 1) * row_pitch + x;
-  send_south[x] = lat[4 * ps + x];
-  send_south[pitch + x] = lat[7 * ps + x];
-  send_south[2 * pitch + x] = lat[8 * ps + x];
-  send_north[x] = lat[2 * ps + top];
-  send_north[pitch + x] = lat[5 * ps + top];
-  send_north[2 * pitch + x] = lat[6 * ps + top];
 }
 
 // sum the per-workgroup partials of up to gridDim.x steps: block s adds partials[s][0..n[s])
