@@ -93,13 +93,14 @@ def cpu_baseline(nx, ny, budget_s=20.0):
                       f"{secs:.2f} s compute"}
 
 
-def pmc_traffic(nx, ny):
-    """HBM bytes per launch from a committed rocprofv3 --pmc summary, if one matches this grid."""
+def pmc_traffic(nx, ny, steps_per_launch):
+    """HBM bytes per launch from a committed rocprofv3 --pmc summary, if one matches this grid
+    and kernel (profiles/pmc_traffic.json, collected as MI355X_MICROARCH.md prescribes)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as fh:
             rec = json.load(fh)
-        return rec.get(f"{nx}x{ny}")
+        return rec.get(f"{nx}x{ny}/steps_per_launch={steps_per_launch}")
     except Exception:
         return None
 
@@ -165,6 +166,7 @@ def main():
 
     av = eng.av_vels(total_steps)          # forces the cross-rank reduce too
     finite = bool(np.isfinite(av).all())
+    steps_per_launch = eng.info()["steps_per_launch"]
     eng.close()
 
     if rank == 0:
@@ -172,9 +174,14 @@ def main():
         mlups = cells * args.steps / elapsed / 1e6
         # per-launch algorithmic bytes: this rank's share of the grid (max over ranks = ceil)
         rows_per_rank = -(-ny // world)
-        algo_bytes = BYTES_PER_UPDATE * nx * rows_per_rank
-        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        traffic = pmc_traffic(nx, ny) if world == 1 else None
+        # one launch of the dominant kernel advances `steps_per_launch` timesteps (the two-step
+        # kernel reads and writes the lattice once per TWO updates): algorithmic bytes per launch =
+        # 72 B x cells x steps_per_launch, launch duration = steps_per_launch x time per step
+        algo_bytes = BYTES_PER_UPDATE * nx * rows_per_rank * steps_per_launch
+        launch_ms = kernel_ms * steps_per_launch
+        achieved = algo_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        traffic = pmc_traffic(nx, ny, steps_per_launch) if world == 1 else None
+        kernel_name = "lbm::step2_stream" if steps_per_launch == 2 else "lbm::step_vec4"
         line = {
             "metric": "MLUPS", "value": mlups, "unit": "MLUPS (million lattice updates/s)",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
@@ -182,11 +189,14 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"D2Q9-BGK timestep loop, {workload}, uniform-equilibrium start",
                        "grid": f"{nx}x{ny}", "math": args.math,
+                       "timesteps_per_memory_pass": steps_per_launch,
                        "decomposition": f"{world} row slab(s), RCCL halo send/recv" if world > 1
                        else "single slab, periodic in-kernel"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes},
+                         "kernel": kernel_name, "steps_per_launch": steps_per_launch,
+                         "launch_ms": launch_ms, "kernel_ms_per_step": kernel_ms,
+                         "algorithmic_bytes_per_launch": algo_bytes},
             "results_finite": finite,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -16,8 +16,9 @@
  * lbm_last_error() holds the message.  There is NO CPU fallback: without a usable HIP device
  * every compute entry point fails.
  *
- * Data layout on the device: structure-of-arrays, 9 planes of fp32, each plane
- * (rows+2) x pitch with one halo row below and above the owned rows; uint8 obstacle mask.
+ * Data layout on the device: structure-of-arrays interleaved by row, fp32 --
+ * value (speed k, row y, column x) at base + (y*9 + k)*pitch + x -- with two halo rows below
+ * and above the rows a slab owns; uint8 obstacle mask.
  * Host-facing arrays keep the reference's layouts: cells are array-of-structures
  * (9 consecutive floats per cell, cell index ii + jj*nx, SerialCode/d2q9-bgk.c:78-81),
  * obstacles are int[ny*nx] with 1 = blocked (:541, :570-601).
@@ -63,6 +64,8 @@ typedef struct {
   int    math_mode;      /* LBM_MATH_EXACT or LBM_MATH_FAST */
   int    world_rank;     /* rank of this context in a multi-process run (0 otherwise) */
   int    world_size;     /* number of processes sharing the grid (1 otherwise) */
+  int    steps_per_launch; /* timesteps one launch of the main kernel advances: 2 when the
+                              two-steps-per-pass kernel is active (large grids), else 1 */
 } lbm_info;
 
 /* ---- error handling -------------------------------------------------------------------- */

@@ -55,7 +55,7 @@ class _CInfo(ctypes.Structure):
     _fields_ = [("n_slabs", ctypes.c_int), ("row_first", ctypes.c_int), ("row_count", ctypes.c_int),
                 ("fluid_cells", ctypes.c_int), ("steps_done", ctypes.c_int),
                 ("math_mode", ctypes.c_int), ("world_rank", ctypes.c_int),
-                ("world_size", ctypes.c_int)]
+                ("world_size", ctypes.c_int), ("steps_per_launch", ctypes.c_int)]
 
 
 @dataclass

@@ -619,17 +619,26 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
     if (sl.blocks_main + sl.blocks_boundary > max_blocks) max_blocks = sl.blocks_main + sl.blocks_boundary;
   }
   // two-steps-per-pass geometry (single periodic slab only)
-  c->band_rows = env_int("LBM_BAND_ROWS", 64);
+  c->band_rows = env_int("LBM_BAND_ROWS", 8);  // 8192^2: bands of 4..48 rows within 2 %; small slabs want short bands
   if (c->band_rows < 1) c->band_rows = 1;
   c->n_strips = ceil_div(params->nx / 4 > 0 ? params->nx / 4 : 1, lbm::kStripQuads);
   c->n_bands = ceil_div(c->row_count, c->band_rows);
-  c->fuse2 = (c->vec4 && env_int("LBM_FUSE2", 0)) ? 1 : 0;
+  // Two timesteps per pass pay once the slab is big enough to be HBM-bound (measured: 8192x1024 and
+  // 4096^2 win, 2048^2 ties, 1024^2 loses; profiles/r01_tuning.md).  LBM_FUSE2=0/1 overrides.
+  {
+    long min_cells = (long)params->nx * params->ny;
+    for (int s = 0; s < n_slabs; s++)
+      if ((long)params->nx * c->slab[s].rows < min_cells) min_cells = (long)params->nx * c->slab[s].rows;
+    if (world > 1) min_cells = (long)params->nx * (params->ny / world);  // every rank must decide alike
+    c->fuse2 = (c->vec4 && env_int("LBM_FUSE2", min_cells >= 6L * 1024 * 1024 ? 1 : 0)) ? 1 : 0;
+  }
   for (int s = 0; s < n_slabs; s++) {
-    // across slabs the two-step kernel needs band_rows >= 2 and slabs of at least 4 rows
-    if (c->halo != HALO_SELF && (c->slab[s].rows < 4 || c->band_rows < 2)) c->fuse2 = 0;
+    // across slabs the two-step kernel needs slabs of at least 4 rows
+    if (c->halo != HALO_SELF && c->slab[s].rows < 4) c->fuse2 = 0;
     const int waves = c->n_strips * (ceil_div(c->slab[s].rows, c->band_rows) + 2);
     if (c->fuse2 && waves > max_blocks) max_blocks = waves;
   }
+  if (world > 1 && params->ny / world < 4) c->fuse2 = 0;
   c->part_stride = round_up(max_blocks, 64);
 
   for (int s = 0; s < n_slabs; s++)
@@ -738,6 +747,7 @@ int lbm_get_info(const lbm_ctx* c, lbm_info* out) {
   out->math_mode = c->math_mode;
   out->world_rank = c->rank;
   out->world_size = c->world;
+  out->steps_per_launch = c->fuse2 ? 2 : 1;
   return LBM_SUCCESS;
 }
 

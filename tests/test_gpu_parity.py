@@ -156,6 +156,40 @@ def test_rccl_self_exchange(lbm, oracle, datasets, monkeypatch):
     np.testing.assert_allclose(got_av, ref_av, rtol=AV_RTOL)
 
 
+@pytest.mark.parametrize("band", [2, 5, 8, 64])
+@pytest.mark.parametrize("slabs,halo", [(1, None), (1, "rccl"), (2, "memcpy"), (3, "memcpy"), (8, "memcpy")])
+def test_two_steps_per_pass_kernel_bitwise(lbm, oracle, datasets, monkeypatch, band, slabs, halo):
+    """The two-timesteps-per-pass kernel (step2_stream: register sliding window, DPP neighbours,
+    2-row halos across slabs) is forced on at test sizes; odd step counts end with a one-step launch.
+    Same per-cell arithmetic, so the lattice stays bit-identical to the oracle."""
+    monkeypatch.setenv("LBM_FUSE2", "1")
+    monkeypatch.setenv("LBM_BAND_ROWS", str(band))
+    if halo:
+        monkeypatch.setenv("LBM_HALO", halo)
+        if slabs == 1:
+            monkeypatch.setenv("LBM_FORCE_HALO", "1")
+    p, ob = datasets("128x256")
+    cells = oracle.init_cells(p)
+    steps = 75                                        # odd: 37 two-step passes + 1 single step
+    ref_cells, ref_av, got_cells, got_av, fields = run_both(lbm, oracle, p, ob, cells, steps, n_gpus=slabs)
+    assert np.array_equal(ref_cells.view(np.uint32), got_cells.view(np.uint32))
+    np.testing.assert_allclose(got_av, ref_av, rtol=AV_RTOL)
+    ref_f = oracle.final_state(p, ref_cells, ob)
+    assert np.array_equal(ref_f["pressure"].view(np.uint32), fields["pressure"].view(np.uint32))
+
+
+def test_two_steps_per_pass_random_lattice(lbm, oracle, monkeypatch):
+    """Random populations / obstacles, both periodic wraps live, lid row next to a slab edge."""
+    monkeypatch.setenv("LBM_FUSE2", "1")
+    monkeypatch.setenv("LBM_BAND_ROWS", "3")
+    monkeypatch.setenv("LBM_HALO", "memcpy")
+    for nx, ny, slabs in ((256, 24, 1), (512, 23, 4), (64, 40, 5), (1024, 9, 2)):
+        p, ob, cells = random_case(lbm, nx, ny, 100 + ny, walls=False)
+        ref_cells, ref_av, got_cells, got_av, _ = run_both(lbm, oracle, p, ob, cells, 20, n_gpus=slabs)
+        assert np.array_equal(ref_cells.view(np.uint32), got_cells.view(np.uint32)), (nx, ny, slabs)
+        np.testing.assert_allclose(got_av, ref_av, rtol=AV_RTOL)
+
+
 def test_rank_api_single_rank_rccl(lbm, oracle, datasets, monkeypatch):
     """lbm_create_rank with a world of one: ncclCommInitRank, halo send/recv to itself and the
     av_vels all-reduce all run through RCCL -- the code path every rank of a torchrun job takes."""
