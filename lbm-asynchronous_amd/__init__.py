@@ -24,7 +24,7 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblbm_hip.so")
+LIB_PATH = os.environ.get("LBM_LIB") or os.path.join(_HERE, "liblbm_hip.so")   # LBM_LIB: experiments only
 CLI_PATH = os.path.join(_HERE, "d2q9-bgk")
 
 MATH_EXACT = 0
