@@ -1,18 +1,23 @@
 """N > 1 path on CPU: world_size 2 and 3 over torch.distributed/gloo.
 
-The GPU engine shards the grid by rows, one slab per rank, and exchanges packed halo rows with
-its ring neighbours every step (lbm_hip.hip: exchange_halos -- the GPU analogue of
-/root/reference/MPI_Waitall/d2q9-bgk.c:225-253).  RCCL needs one GPU per rank, which the builder
-container and the 1-GPU box lack, so this test replays the SAME protocol on CPU ranks:
+The GPU engine shards the grid by rows, one slab per rank, keeps two halo rows around every slab
+and, once per pass, ships WHOLE boundary rows to its ring neighbours (lbm_hip.hip: exchange_halos --
+the GPU analogue of /root/reference/MPI_Waitall/d2q9-bgk.c:225-253); a pass advances TWO timesteps
+when the two-step kernel is active (halo depth 2), else one.  RCCL needs one GPU per rank, which
+the builder container and the 1-GPU box lack, so this test replays the SAME protocol on CPU ranks:
 
   * rows from the product's own lbm_partition_rows (C ABI, host-only call);
-  * per step: send_north = planes 2,5,6 of the top owned row to rank+1, send_south = planes
-    4,7,8 of the bottom owned row to rank-1, recv_south from rank-1, recv_north from rank+1, in
-    the engine's posting order (which must pair correctly when rank+1 == rank-1, world_size 2);
-  * interior rows first, boundary rows after the halos arrived (the Waitall pattern);
-  * the lid row (global ny-2) accelerated by whichever rank owns it;
-  * per-step partial sums of |u| all-reduced at the end (MPI/d2q9-bgk.c:298-309) and divided by
-    the global fluid-cell count; rows gathered on rank 0 (MPI/d2q9-bgk.c:265-295).
+  * per pass: my top `depth` rows -> rank+1's south halo, my bottom `depth` rows -> rank-1's north
+    halo, posted in the engine's order (send N, send S, recv S, recv N), which must pair correctly
+    when rank+1 == rank-1 (world_size 2);
+  * rows that touch no halo first, the rest after the halos arrived (the Waitall pattern);
+  * two-step pass: step t is relaxed on rows -1..rows (the two halo-adjacent rows redundantly,
+    exactly as the neighbour relaxes them), step t+1 on the owned rows; the lid row (global ny-2)
+    is accelerated wherever a rank holds a copy of it, owned or halo;
+  * an odd step count ends with a one-step pass (halo depth 1);
+  * per-step partial sums of |u| over OWNED rows all-reduced at the end
+    (MPI/d2q9-bgk.c:298-309) and divided by the global fluid-cell count; rows gathered on rank 0
+    (MPI/d2q9-bgk.c:265-295).
 
 The slab arithmetic is the CPU oracle's fused row-range form (test infrastructure); the result
 must equal the single-domain oracle bit for bit.  The same decomposition is checked on real
@@ -49,46 +54,86 @@ def rank_main(rank, world, port, name, steps, out_dir):
         p, ob = conftest.dataset(name)
         first, rows = lbm.partition_rows(p.ny, world, rank)
         north, south = (rank + 1) % world, (rank - 1 + world) % world
-        lid = p.ny - 2
-        accel_row = lid - first + 1 if first <= lid < first + rows else 0   # 1-based slab row
+        H = 2                                                  # halo rows kept around the slab
+        # local index (-1 .. rows) of the lid row if this rank holds a copy of it, else None
+        lid_local = None
+        for shift in (-p.ny, 0, p.ny):
+            loc = p.ny - 2 + shift - first
+            if -1 <= loc <= rows:
+                lid_local = loc
 
-        full = np.ascontiguousarray(oracle.init_cells(p).transpose(2, 0, 1))   # (9, ny, nx)
-        src = np.zeros((9, rows + 2, p.nx), dtype=np.float32)
-        src[:, 1:rows + 1] = full[:, first:first + rows]
-        dst = np.zeros_like(src)
-        mask = np.ascontiguousarray(ob[first:first + rows])
+        full = np.ascontiguousarray(oracle.init_cells(p).transpose(2, 0, 1))      # (9, ny, nx)
+        S = np.zeros((9, rows + 2 * H, p.nx), dtype=np.float32)                   # array row = local row + H
+        S[:, H:H + rows] = full[:, first:first + rows]
+        T = np.zeros_like(S)
+        U = np.zeros_like(S)
+        # mask of local rows -1 .. rows (periodic neighbours), as the engine uploads it
+        mask = np.ascontiguousarray(ob[[(first + r) % p.ny for r in range(-1, rows + 1)]])
         tot_u = np.zeros(steps, dtype=np.float64)
+        ps = (rows + 2 * H) * p.nx
 
-        for t in range(steps):
-            # accelerate first: the halo rows that leave this rank must already carry it
-            # (the engine fuses it into the previous step's kernel; same values)
-            if accel_row:
-                oracle.lib.lbm_oracle_accelerate_row_soa(
-                    p.nx, p.density, p.accel, src.ctypes.data, (rows + 2) * p.nx,
-                    mask[accel_row - 1].ctypes.data, accel_row)
-            send_north = torch.from_numpy(np.ascontiguousarray(src[[2, 5, 6], rows]))
-            send_south = torch.from_numpy(np.ascontiguousarray(src[[4, 7, 8], 1]))
-            recv_south = torch.empty_like(send_north)
-            recv_north = torch.empty_like(send_south)
+        def accelerate(arr, local_row):
+            oracle.lib.lbm_oracle_accelerate_row_soa(p.nx, p.density, p.accel, arr.ctypes.data, ps,
+                                                     mask[local_row + 1].ctypes.data, local_row + H)
+
+        def relax(src, dst, lo, hi):
+            """advance local rows lo..hi (inclusive) of src into dst; returns sum |u| of those rows"""
+            if hi < lo:
+                return 0.0
+            return oracle.fused_rows(p.nx, rows + 2, p.density, p.accel, p.omega, src, dst, mask, 0,
+                                     lo + H, hi + H)
+
+        def exchange(arr, depth):
+            send_n = torch.from_numpy(np.ascontiguousarray(arr[:, H + rows - depth:H + rows]))
+            send_s = torch.from_numpy(np.ascontiguousarray(arr[:, H:H + depth]))
+            recv_s, recv_n = torch.empty_like(send_n), torch.empty_like(send_s)
             # the engine's posting order: send N, send S, recv S, recv N
-            ops = [dist.P2POp(dist.isend, send_north, north), dist.P2POp(dist.isend, send_south, south),
-                   dist.P2POp(dist.irecv, recv_south, south), dist.P2POp(dist.irecv, recv_north, north)]
-            reqs = dist.batch_isend_irecv(ops)
-            # interior rows overlap with the exchange
-            s_in = oracle.fused_rows(p.nx, rows, p.density, p.accel, p.omega, src, dst, mask, 0, 2, rows - 1)
-            for r in reqs:
-                r.wait()
-            src[[2, 5, 6], 0] = recv_south.numpy()
-            src[[4, 7, 8], rows + 1] = recv_north.numpy()
-            s_b0 = oracle.fused_rows(p.nx, rows, p.density, p.accel, p.omega, src, dst, mask, 0, 1, 1)
-            s_b1 = oracle.fused_rows(p.nx, rows, p.density, p.accel, p.omega, src, dst, mask, 0, rows, rows)
-            tot_u[t] = float(s_in) + float(s_b0) + float(s_b1)
-            src, dst = dst, src
+            ops = [dist.P2POp(dist.isend, send_n, north), dist.P2POp(dist.isend, send_s, south),
+                   dist.P2POp(dist.irecv, recv_s, south), dist.P2POp(dist.irecv, recv_n, north)]
+            return dist.batch_isend_irecv(ops), recv_s, recv_n
+
+        def land(arr, depth, recv_s, recv_n):
+            arr[:, H - depth:H] = recv_s.numpy()
+            arr[:, H + rows:H + rows + depth] = recv_n.numpy()
+
+        t = 0
+        while t < steps:
+            two = t + 1 < steps
+            depth = 2 if two else 1
+            # accelerate_flow of step t on the owned copy; the halo copies arrive already accelerated
+            if lid_local is not None and 0 <= lid_local < rows:
+                accelerate(S, lid_local)
+            reqs, recv_s, recv_n = exchange(S, depth)
+            if two:
+                # step t on the rows whose inputs are all owned (overlaps the exchange) ...
+                s_in = relax(S, T, 1, rows - 2)
+                for r in reqs:
+                    r.wait()
+                land(S, depth, recv_s, recv_n)
+                # ... then on rows -1, 0 and rows-1, rows (halo-dependent; -1 and rows redundantly)
+                relax(S, T, -1, -1)
+                s_b = relax(S, T, 0, 0) + relax(S, T, rows - 1, rows - 1)
+                relax(S, T, rows, rows)
+                tot_u[t] = float(s_in) + float(s_b)
+                # accelerate_flow of step t+1 on every copy of the lid row this rank holds
+                if lid_local is not None:
+                    accelerate(T, lid_local)
+                tot_u[t + 1] = float(relax(T, U, 0, rows - 1))
+                S, U = U, S
+                t += 2
+            else:
+                s_in = relax(S, T, 1, rows - 2)
+                for r in reqs:
+                    r.wait()
+                land(S, depth, recv_s, recv_n)
+                tot_u[t] = float(s_in) + float(relax(S, T, 0, 0)) + float(relax(S, T, rows - 1, rows - 1))
+                S, T = T, S
+                t += 1
 
         tot = torch.from_numpy(tot_u)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         av = (tot.numpy().astype(np.float32) / np.float32((ob == 0).sum())).astype(np.float32)
-        mine = torch.from_numpy(np.ascontiguousarray(src[:, 1:rows + 1]))
+        mine = torch.from_numpy(np.ascontiguousarray(S[:, H:H + rows]))
         if rank == 0:
             result = np.empty((9, p.ny, p.nx), dtype=np.float32)
             result[:, first:first + rows] = mine.numpy()
@@ -105,7 +150,7 @@ def rank_main(rank, world, port, name, steps, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,name,steps", [(2, "128x128", 60), (3, "128x256", 40)])
+@pytest.mark.parametrize("world,name,steps", [(2, "128x128", 61), (3, "128x256", 40)])
 def test_row_sharded_ring_equals_single_domain(tmp_path, oracle, datasets, lbm, world, name, steps):
     torch.set_num_threads(1)
     mp.spawn(rank_main, args=(world, free_port(), name, steps, str(tmp_path)), nprocs=world, join=True)
