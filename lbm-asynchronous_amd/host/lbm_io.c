@@ -5,6 +5,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include "lbm_io.h"
 
@@ -85,19 +88,57 @@ int* lbm_tile_obstacles(const int* tile, int tile_nx, int tile_ny, int nx, int n
   return map;
 }
 
+/* one line per cell is ~85 bytes of printf work; 8192^2 is 5.7 GB of text.  Rows are formatted by
+ * all cores into per-thread buffers (snprintf, so the bytes are exactly what the reference's
+ * fprintf produces) and written out in order. */
+#define LBM_LINE_MAX 128 /* "%d %d" + 4 x "%.12E" (<= 20 chars each) + " %d\n" */
+
 void lbm_write_final_state_rows(FILE* fp, const lbm_params* params, int row_first, int row_count,
                                 const float* u_x, const float* u_y, const float* u_mag,
                                 const float* pressure, const int* obstacles)
 {
   const int nx = params->nx;
-  for (int r = 0; r < row_count; r++) {
-    const int jj = row_first + r;
-    for (int ii = 0; ii < nx; ii++) {
-      const size_t c = (size_t)r * nx + ii;
-      fprintf(fp, "%d %d %.12E %.12E %.12E %.12E %d\n", ii, jj, u_x[c], u_y[c], u_mag[c],
-              pressure[c], obstacles[(size_t)jj * nx + ii]);
-    }
+  int n_threads = 1;
+#ifdef _OPENMP
+  n_threads = omp_get_max_threads();
+#endif
+  /* rows per thread and round: keep each buffer around 4 MiB */
+  int rows_per_task = (int)((4L << 20) / ((long)nx * LBM_LINE_MAX));
+  if (rows_per_task < 1) rows_per_task = 1;
+  const size_t buf_bytes = (size_t)rows_per_task * nx * LBM_LINE_MAX;
+  char** buf = (char**)malloc(sizeof(char*) * (size_t)n_threads);
+  size_t* used = (size_t*)malloc(sizeof(size_t) * (size_t)n_threads);
+  if (buf == NULL || used == NULL) lbm_die("cannot allocate memory for output buffers", __LINE__, __FILE__);
+  for (int t = 0; t < n_threads; t++) {
+    buf[t] = (char*)malloc(buf_bytes);
+    if (buf[t] == NULL) lbm_die("cannot allocate memory for output buffers", __LINE__, __FILE__);
   }
+
+  for (int r0 = 0; r0 < row_count; r0 += rows_per_task * n_threads) {
+#pragma omp parallel for schedule(static, 1)
+    for (int t = 0; t < n_threads; t++) {
+      const int begin = r0 + t * rows_per_task;
+      int end = begin + rows_per_task;
+      if (end > row_count) end = row_count;
+      char* out = buf[t];
+      for (int r = begin; r < end; r++) {
+        const int jj = row_first + r;
+        for (int ii = 0; ii < nx; ii++) {
+          const size_t c = (size_t)r * nx + ii;
+          /* the reference's format, SerialCode/d2q9-bgk.c:722 */
+          out += snprintf(out, LBM_LINE_MAX, "%d %d %.12E %.12E %.12E %.12E %d\n", ii, jj, u_x[c], u_y[c],
+                          u_mag[c], pressure[c], obstacles[(size_t)jj * nx + ii]);
+        }
+      }
+      used[t] = (size_t)(out - buf[t]);
+    }
+    for (int t = 0; t < n_threads; t++)
+      if (used[t] > 0 && fwrite(buf[t], 1, used[t], fp) != used[t])
+        lbm_die("could not write file output file", __LINE__, __FILE__);
+  }
+  for (int t = 0; t < n_threads; t++) free(buf[t]);
+  free(buf);
+  free(used);
 }
 
 void lbm_write_av_vels(const char* path, const float* av_vels, int n)
