@@ -119,6 +119,35 @@ def test_8192_short_run_bitwise_vs_oracle(lbm, oracle, big_case):
     assert not fields["u"][ob == 1].any()
 
 
+def test_cli_8192_tiled_run_against_oracle_cli(lbm, oracle, tmp_path):
+    """SURVEY.md section 8d parity run at BASELINE's full size, through both command lines: the
+    C host program on the GPU vs the CPU oracle program on the same files (1024x1024 obstacle file
+    tiled 8x8 with LBM_TILE), 24 steps; compared on the binary fp32 pressure dump (bit for bit) and
+    on av_vels.dat (check.py rule) -- the 5.7 GB text file is not written."""
+    import oracle_binding
+    pf = tmp_path / "big.params"
+    pf.write_text("8192\n8192\n24\n10\n0.1\n0.01\n1.85\n")
+    of = os.path.join(GOLDEN, "inputs", "obstacles_1024x1024.dat")
+    env = dict(os.environ, LBM_TILE="1024x1024", LBM_OUTPUT="none")
+    (tmp_path / "gpu").mkdir(); (tmp_path / "cpu").mkdir()
+    g = subprocess.run([lbm.CLI_PATH, str(pf), of], cwd=tmp_path / "gpu", capture_output=True, text=True,
+                       env=dict(env, LBM_PRESSURE_BIN="pressure.bin"))
+    assert g.returncode == 0, g.stderr
+    c = subprocess.run([oracle_binding.CLI, str(pf), of], cwd=tmp_path / "cpu", capture_output=True, text=True,
+                       env=dict(env, LBM_PRESSURE_BIN="pressure.bin", LBM_ORACLE_FORM="fused"))
+    assert c.returncode == 0, c.stderr
+    pg = np.fromfile(tmp_path / "gpu" / "pressure.bin", dtype=np.uint32)
+    pc = np.fromfile(tmp_path / "cpu" / "pressure.bin", dtype=np.uint32)
+    assert pg.size == 8192 * 8192 and np.array_equal(pg, pc)
+    av_g = np.loadtxt(tmp_path / "gpu" / "av_vels.dat", usecols=[1])
+    av_c = np.loadtxt(tmp_path / "cpu" / "av_vels.dat", usecols=[1])
+    assert lbm.check_passes(av_c, av_g)
+    np.testing.assert_allclose(av_g, av_c, rtol=2e-3)
+    re_g = float(g.stdout.splitlines()[1].split()[-1])
+    re_c = float(c.stdout.splitlines()[1].split()[-1])
+    assert re_g == pytest.approx(re_c, rel=2e-3)
+
+
 def test_8192_properties(lbm, big_case):
     p, ob = big_case
     with lbm.Engine(p, ob, None) as eng, lbm.Engine(p, ob, None) as split:
