@@ -135,7 +135,12 @@ def main():
     total_steps = args.warmup + args.steps
     p, ob, workload = synthetic_case(lbm, nx, ny, total_steps)
 
-    if world > 1:
+    # LBM_BENCH_RANK_API=1 takes the one-process-per-GPU code path even for a world of one
+    # (rehearsal of the torchrun path on a 1-GPU box)
+    use_rank_api = world > 1 or os.environ.get("LBM_BENCH_RANK_API") == "1"
+    if use_rank_api and "MASTER_ADDR" not in os.environ:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
+    if use_rank_api:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         uid = [lbm.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
@@ -147,7 +152,7 @@ def main():
     def fence():
         eng.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_rank_api:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -159,7 +164,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
-    if world > 1:
+    if use_rank_api:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
@@ -211,7 +216,7 @@ def main():
                 line["cpu_baseline"] = base
         print(json.dumps(line), flush=True)
 
-    if world > 1:
+    if use_rank_api:
         dist.destroy_process_group()
 
 
