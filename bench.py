@@ -93,6 +93,38 @@ def cpu_baseline(nx, ny, budget_s=20.0):
                       f"{secs:.2f} s compute"}
 
 
+def cpu_reference(budget_steps=300):
+    """The reference program itself (oracle/_ref/d2q9-bgk-serial-portable: SerialCode/d2q9-bgk.c
+    compiled unmodified by oracle/Makefile in the builder container) timed on this host on the
+    reference's own 1024x1024 data set with a shortened iteration count.  Extra information beside
+    cpu_baseline: the reference binary always writes its 91 MB final_state.dat, so it cannot be run
+    on the 8192x8192 workload (5.7 GB of text)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "d2q9-bgk-serial-portable")
+    if not os.path.exists(exe):
+        return None
+    inputs = os.path.join(ROOT, "tests", "golden", "inputs")
+    with tempfile.TemporaryDirectory() as tmp:
+        pf = os.path.join(tmp, "in.params")
+        with open(pf, "w") as fh:
+            fh.write(f"1024\n1024\n{budget_steps}\n10\n0.1\n0.01\n1.85\n")
+        try:
+            out = subprocess.run([exe, pf, os.path.join(inputs, "obstacles_1024x1024.dat")], cwd=tmp,
+                                 capture_output=True, text=True, timeout=120,
+                                 env=dict(os.environ, OMP_NUM_THREADS="1"))
+        except Exception:
+            return None
+    if out.returncode != 0:
+        return None
+    for line in out.stdout.splitlines():
+        if line.startswith("Elapsed Compute time"):
+            secs = float(line.split()[-2])
+            return {"value": 1024 * 1024 * budget_steps / secs / 1e6, "unit": "MLUPS", "cores": 1,
+                    "kind": "reference",
+                    "sample": f"{budget_steps} steps of the reference's 1024x1024 data set, "
+                              f"oracle/_ref/d2q9-bgk-serial-portable, {secs:.2f} s compute"}
+    return None
+
+
 def pmc_traffic(nx, ny, steps_per_launch):
     """HBM bytes per launch from a committed rocprofv3 --pmc summary, if one matches this grid
     and kernel (profiles/pmc_traffic.json, collected as MI355X_MICROARCH.md prescribes)."""
@@ -214,6 +246,9 @@ def main():
             base = cpu_baseline(nx, ny)
             if base:
                 line["cpu_baseline"] = base
+            ref = cpu_reference()
+            if ref:
+                line["cpu_reference_1024x1024"] = ref
         print(json.dumps(line), flush=True)
 
     if use_rank_api:

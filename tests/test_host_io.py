@@ -64,6 +64,24 @@ def test_bad_obstacle_lines(cli, lbm, tmp_path, line, msg):
         lbm.read_obstacles(str(tmp_path / "ob.dat"), 16, 8)
 
 
+def test_empty_and_duplicate_obstacle_lines(lbm, tmp_path):
+    """An empty obstacle file is a grid without obstacles; duplicate lines are allowed
+    (the reference just assigns the flag again, SerialCode/d2q9-bgk.c:588-601)."""
+    (tmp_path / "empty.dat").write_text("")
+    assert lbm.read_obstacles(str(tmp_path / "empty.dat"), 16, 8).sum() == 0
+    (tmp_path / "dup.dat").write_text("3 2 1\n3 2 1\n15 7 1\n")
+    ob = lbm.read_obstacles(str(tmp_path / "dup.dat"), 16, 8)
+    assert ob.sum() == 2 and ob[2, 3] == 1 and ob[7, 15] == 1
+    # the C reader agrees (through the oracle CLI, which links the product's lbm_io.c)
+    (tmp_path / "in.params").write_text("16\n8\n2\n10\n0.1\n0.005\n1.85\n")
+    out = run([oracle_binding.CLI, "in.params", "dup.dat"], tmp_path)
+    assert out.returncode == 0, out.stderr
+    flags = np.loadtxt(tmp_path / "final_state.dat", usecols=[6]).reshape(8, 16)
+    assert np.array_equal(flags.astype(np.int32), ob)
+    out = run([oracle_binding.CLI, "in.params", "empty.dat"], tmp_path)
+    assert out.returncode == 0 and np.loadtxt(tmp_path / "final_state.dat", usecols=[6]).sum() == 0
+
+
 def test_missing_obstacle_file(cli, tmp_path):
     (tmp_path / "in.params").write_text("16\n8\n10\n10\n0.1\n0.005\n1.85\n")
     out = run([cli, "in.params", "absent.dat"], tmp_path)
