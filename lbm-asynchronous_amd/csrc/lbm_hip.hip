@@ -619,9 +619,31 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
     if (sl.blocks_main + sl.blocks_boundary > max_blocks) max_blocks = sl.blocks_main + sl.blocks_boundary;
   }
   // two-steps-per-pass geometry (single periodic slab only)
-  c->band_rows = env_int("LBM_BAND_ROWS", 8);  // 8192^2: bands of 4..48 rows within 2 %; small slabs want short bands
-  if (c->band_rows < 1) c->band_rows = 1;
   c->n_strips = ceil_div(params->nx / 4 > 0 ? params->nx / 4 : 1, lbm::kStripQuads);
+  // Band height of the two-step kernel.  A wave sweeps band_rows + 2 rows; 256 CUs x 12 waves
+  // (3 per SIMD at 138 VGPRs) are resident at once.  Big slabs run many rounds of waves and like
+  // short bands (8: measured best at 8192^2 and 4096^2).  A slab that fits in a few rounds is
+  // quantised by them: pick the height that fills k rounds exactly (measured on 8192x1024:
+  // 12 rows = 0.95 rounds 76.7 us, 11 rows = 1.04 rounds 87.7 us; profiles/r01_tuning.md).
+  {
+    const long resident = 256L * 12;
+    const long slab_rows = (n_slabs > 1 || world > 1) ? (c->row_count / n_slabs) - 4 : c->row_count;
+    const long rows_eff = slab_rows > 1 ? slab_rows : 1;
+    int pick = 8;
+    if ((long)c->n_strips * ceil_div(rows_eff, 8) < 5 * resident) {
+      long best_cost = -1;
+      for (int k = 1; k <= 4; k++) {
+        long b = (rows_eff * c->n_strips + k * resident - 1) / (k * resident);
+        if (b < 4) b = 4;
+        if (b > 32) b = 32;
+        const long rounds = ((long)c->n_strips * ceil_div(rows_eff, b) + resident - 1) / resident;
+        const long cost = rounds * (b + 2);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; pick = (int)b; }
+      }
+    }
+    c->band_rows = env_int("LBM_BAND_ROWS", pick);
+  }
+  if (c->band_rows < 1) c->band_rows = 1;
   c->n_bands = ceil_div(c->row_count, c->band_rows);
   // Two timesteps per pass pay once the slab is big enough to be HBM-bound (measured: 8192x1024 and
   // 4096^2 win, 2048^2 ties, 1024^2 loses; profiles/r01_tuning.md).  LBM_FUSE2=0/1 overrides.

@@ -101,7 +101,7 @@ int main(int argc, char** argv) {
   const int nx = argc > 1 ? atoi(argv[1]) : 8192;
   const int ny = argc > 2 ? atoi(argv[2]) : 8192;
   const int rounds = argc > 3 ? atoi(argv[3]) : 3;
-  const int iters = 20;
+  const int iters = getenv("TUNE_ITERS") ? atoi(getenv("TUNE_ITERS")) : 20;
   const long cells = (long)nx * ny;
   const long max_pad = 1 << 20;
   const long ps_max = cells + max_pad + 2048L * ny / 9;  // also covers row-interleaved pads up to 2048 floats
@@ -126,8 +126,11 @@ int main(int argc, char** argv) {
   std::vector<Variant> vars = {
       {"exact loads nt       ", step_vec4<0, 0, true, 256, false>, 256},
       {"exact loads          ", step_vec4<0, 0, false, 256, false>, 256},
-      {"exact loads nt  snake", step_vec4<0, 0, true, 256, false>, 256, 1},
-      {"exact loads     snake", step_vec4<0, 0, false, 256, false>, 256, 1},
+      {"fast  loads          ", step_vec4<1, 0, false, 256, false>, 256},
+      {"copy  loads          ", step_vec4<2, 0, false, 256, false>, 256},
+      {"exact loads b128     ", step_vec4<0, 0, false, 128, false>, 128},
+      {"exact loads b64      ", step_vec4<0, 0, false, 64, false>, 64},
+      {"copy  loads b64      ", step_vec4<2, 0, false, 64, false>, 64},
   };
   std::vector<long> pads = {0, 320, 1088, 8256};
   std::vector<int> occs = {0};  // 0 = no cap; k = at most k workgroups (4 waves each) per CU
@@ -185,7 +188,7 @@ int main(int argc, char** argv) {
         memset(&a, 0, sizeof(a));
         a.mask = mask; a.plane_stride = interleave ? nx + pad : ps; a.pitch = nx;
         a.row_pitch = interleave ? 9L * (nx + pad) : nx; a.nx = nx; a.rows = ny; a.row_first = 0;
-        a.row_stride = 1; a.n_rows = ny; a.omega = 1.85f;
+        a.row_stride = 1; a.n_rows = ny; a.omega = 1.85f; a.wrap = 1;
         a.a1 = 0.1f * 0.01f / 9.f; a.a2 = 0.1f * 0.01f / 36.f; a.accel_row = ny - 2; a.partials = partials;
         const int grid = (int)(((long)(nx / 4) * ny + v.block - 1) / v.block);
         float* L[2] = {A, B + boff};
