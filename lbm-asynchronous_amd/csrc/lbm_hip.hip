@@ -116,7 +116,7 @@ struct lbm_ctx {
   int nts = 1;    // nontemporal stores (LBM_NTS overrides)
   int snake = 0;  // alternate the sweep direction every step (LBM_SNAKE overrides)
   int fuse2 = 0;  // two timesteps per pass (step2_stream) when a single periodic slab allows it
-  int band_rows = 64, n_strips = 0, n_bands = 0;  // step2_stream geometry
+  int band_rows = 8, n_strips = 0;  // step2_stream geometry: band height, waves across x
 };
 
 namespace {
@@ -168,7 +168,7 @@ int launch_step(lbm_ctx* c, int s, hipStream_t stream, int row_first, int row_st
   return LBM_SUCCESS;
 }
 
-// two timesteps in one pass over the rows [row_first, row_end) of slab s, cut into n_bands bands of
+// two timesteps in one pass over the rows [row_first, row_end) of slab s, cut into band_count bands of
 // band_rows rows that start band_pitch rows apart; writes the partials of steps t and t+1 into
 // slots slot_fill and slot_fill+1
 int launch_step2(lbm_ctx* c, int s, hipStream_t stream, int row_first, int row_end, int band_rows,
@@ -298,7 +298,7 @@ int flush_partials(lbm_ctx* c, int step_base) {
 //                            ▲ waits I(t-1)
 //
 // I(t) and B(t) both read lattice t and write disjoint rows of lattice t+1; B(t) additionally
-// needs the halos X(t) (its own stream, in order) and writes the packed rows X(t+1) sends.  The
+// needs the halos X(t) (its own stream, in order) and writes the boundary rows X(t+1) sends.  The
 // chain of interior kernels is the critical path; exchange and boundary rows hide beside it.
 int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
   if (!c) LBM_FAIL(LBM_FAILURE, "lbm_run: null context");
@@ -644,7 +644,6 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
     c->band_rows = env_int("LBM_BAND_ROWS", pick);
   }
   if (c->band_rows < 1) c->band_rows = 1;
-  c->n_bands = ceil_div(c->row_count, c->band_rows);
   // Two timesteps per pass pay once the slab is big enough to be HBM-bound (measured: 8192x1024 and
   // 4096^2 win, 2048^2 ties, 1024^2 loses; profiles/r01_tuning.md).  LBM_FUSE2=0/1 overrides.
   {

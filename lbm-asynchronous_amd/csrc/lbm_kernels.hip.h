@@ -1,23 +1,27 @@
 // lbm_kernels.hip.h -- CDNA4 (gfx950) device code of the D2Q9-BGK engine.
 //
-// One fused kernel per timestep replaces the reference's five sweeps
+// One fused kernel replaces the reference's five sweeps per timestep
 // (accelerate_flow, propagate, rebound, collision, av_velocity;
 // /root/reference/SerialCode/d2q9-bgk.c:207-458):
 //   pull-stream 9 populations from the neighbours (periodic in x; in y either periodic or fed by
-//   packed halo rows), bounce back on blocked cells, BGK-relax fluid cells, sum |u| of the
-//   relaxed cells into one partial per workgroup, and apply NEXT step's accelerate_flow to the
-//   lid row before storing (so no separate pass over that row is needed).
+//   halo rows stored around the slab), bounce back on blocked cells, BGK-relax fluid cells, sum
+//   |u| of the relaxed cells into one partial per workgroup, and apply the NEXT step's
+//   accelerate_flow to the lid row before storing (so no separate pass over that row is needed).
+// step_vec4 / step_scalar advance one timestep per pass over memory, step2_stream two.
 //
 // Layout: structure of arrays interleaved by row -- value (k, y, x) lives at
 // base + y*row_pitch + k*plane_stride + x with plane_stride = pitch and row_pitch = 9*pitch, i.e.
-// the 9 planes of one row lie next to each other (36*nx bytes), rows follow each other.  Every
-// access is still a contiguous, 16-byte-aligned run along x of ONE speed (fully coalesced), but a
-// workgroup's 9+9 streams now fall into a ~1 MB window instead of 18 windows 256 MiB apart:
-// measured 10-13 % faster than 9 whole-grid planes on MI355X (profiles/r01_tuning.md).  Each value is read exactly once and written exactly once per step: the
-// algorithmic traffic is 72 B per lattice update, and there is no reuse to stage in LDS or to
-// feed MFMA -- this kernel is bound by HBM bandwidth.  Each lane owns 4 consecutive cells and
-// moves every plane with one 16-byte access; the +-1 column shifts of the six x-moving
-// populations are assembled from the lane's own aligned vector plus one neighbour dword.
+// the 9 planes of one row lie next to each other (36*nx bytes), rows follow each other, and two
+// halo rows sit below row 0 and above row rows-1.  Every access is a contiguous, 16-byte-aligned
+// run along x of ONE speed (fully coalesced), and a workgroup's 9+9 streams fall into a ~1 MB
+// window instead of 18 windows 256 MiB apart: measured 10-13 % faster than 9 whole-grid planes on
+// MI355X (profiles/r01_tuning.md).
+//
+// Each value is read exactly once and written exactly once per step: the algorithmic traffic is
+// 72 B per lattice update, and there is no reuse to stage in LDS or to feed MFMA.  The one-step
+// kernel is bound by HBM bandwidth: each lane owns 4 consecutive cells and moves every plane with
+// one 16-byte access; the +-1 column shifts of the six x-moving populations are assembled from
+// the lane's own aligned vector plus one neighbour dword.
 //
 // Speed numbering (SerialCode/d2q9-bgk.c:9-15):   6 2 5
 //                                                  3 0 1
@@ -45,7 +49,7 @@ struct StepArgs {
   float* dst;                 // plane 0 of the destination lattice
   const unsigned char* mask;  // rows x pitch, 1 = blocked
   long plane_stride;          // floats between planes
-  int pitch;                  // floats between rows of the mask and of the packed halo rows
+  int pitch;                  // bytes between rows of the uint8 mask
   long row_pitch;             // floats between lattice rows of one plane
   int nx;                     // cells per row
   int rows;                   // rows owned by this slab
