@@ -154,6 +154,9 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    # RCCL prints a five-line version banner on stdout at communicator creation unless told not to;
+    # stdout must carry exactly one JSON line (errors are still reported at this level)
+    os.environ.setdefault("NCCL_DEBUG", "ERROR")
     import torch
     import torch.distributed as dist
 
