@@ -155,6 +155,30 @@ def test_cli_8192_tiled_run_against_oracle_cli(lbm, oracle, tmp_path):
     assert re_g == pytest.approx(re_c, rel=2e-3)
 
 
+def test_8192_two_kernels_agree_bitwise_after_1001_steps(lbm, big_case, monkeypatch):
+    """Size-independent cross-check at BASELINE's full size: the one-step kernel and the
+    two-steps-per-pass kernel are independent implementations of the same arithmetic (different
+    data flow, different neighbour exchange); after 1001 steps on 8192x8192 (odd: the two-step run
+    ends with a one-step launch) their pressure and velocity fields must be bit-identical and mass
+    conserved."""
+    p0, ob = big_case
+    p = lbm.Params(p0.nx, p0.ny, 1001, p0.reynolds_dim, p0.density, p0.accel, p0.omega)
+    out = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("LBM_FUSE2", fuse)
+        with lbm.Engine(p, ob, None) as eng:
+            assert eng.info()["steps_per_launch"] == (2 if fuse == "1" else 1)
+            m0 = eng.total_density()
+            eng.run(1001)
+            assert eng.total_density() == pytest.approx(m0, rel=1e-6)
+            f = eng.final_state()
+            out[fuse] = (f["pressure"].copy(), f["u"].copy(), eng.av_vels(1001))
+    assert np.array_equal(out["0"][0].view(np.uint32), out["1"][0].view(np.uint32))
+    assert np.array_equal(out["0"][1].view(np.uint32), out["1"][1].view(np.uint32))
+    np.testing.assert_allclose(out["0"][2], out["1"][2], rtol=1e-6)
+    assert np.isfinite(out["1"][2]).all() and out["1"][2][-1] > out["1"][2][0] > 0
+
+
 def test_8192_properties(lbm, big_case):
     p, ob = big_case
     with lbm.Engine(p, ob, None) as eng, lbm.Engine(p, ob, None) as split:
