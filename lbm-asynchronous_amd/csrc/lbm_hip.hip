@@ -211,9 +211,6 @@ int launch_step2(lbm_ctx* c, int s, hipStream_t stream, int row_first, int row_e
   return LBM_SUCCESS;
 }
 
-// Two-step kernel across slabs: an output row y reads source rows y-2 .. y+2, so only rows 0,1 and
-// rows-2, rows-1 touch halo rows.  They form two 2-row bands (short sweeps: low latency on the comm
-// stream); rows [2, rows-2) are the interior region, cut into bands of band_rows.
 int blocks_for_rows(const lbm_ctx* c, int n_rows) {
   if (n_rows <= 0) return 0;
   return c->vec4 ? ceil_div((long)(c->p.nx / 4) * n_rows, lbm::kBlock)
@@ -289,7 +286,7 @@ int flush_partials(lbm_ctx* c, int step_base) {
   return LBM_SUCCESS;
 }
 
-// The timestep loop.  Single slab: one fused launch per step.  Several slabs / ranks
+// The timestep loop.  Single slab: one fused launch per pass (one or two timesteps).  Several slabs / ranks
 // (the Waitall pattern of MPI_Waitall/d2q9-bgk.c:225-253, restructured for two HIP streams):
 //
 //   compute stream:  I(0) ─────────────► I(1) ─────────────► I(2) ...     interior rows 1..rows-2
@@ -300,6 +297,10 @@ int flush_partials(lbm_ctx* c, int step_base) {
 // I(t) and B(t) both read lattice t and write disjoint rows of lattice t+1; B(t) additionally
 // needs the halos X(t) (its own stream, in order) and writes the boundary rows X(t+1) sends.  The
 // chain of interior kernels is the critical path; exchange and boundary rows hide beside it.
+//
+// Two-step passes across slabs: an output row y reads source rows y-2 .. y+2, so only rows 0,1 and
+// rows-2, rows-1 touch halo rows.  They form two 2-row bands (short sweeps: low latency on the comm
+// stream); rows [2, rows-2) are the interior region, cut into bands of band_rows.
 int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
   if (!c) LBM_FAIL(LBM_FAILURE, "lbm_run: null context");
   if (n_steps < 0) LBM_FAIL(LBM_FAILURE, "lbm_run: negative step count");
