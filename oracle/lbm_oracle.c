@@ -123,23 +123,28 @@ void lbm_oracle_accelerate_flow(const lbm_oracle_params* p, float* cells, const 
 
 void lbm_oracle_propagate(const lbm_oracle_params* p, const float* cells, float* tmp_cells)
 {
-  /* periodic pull, SerialCode/d2q9-bgk.c:251-273: speed k arrives from (x - cx_k, y - cy_k) */
+  /* periodic pull, SerialCode/d2q9-bgk.c:251-273: speed k arrives from (x - cx_k, y - cy_k).
+   * Row pointers for the three source rows, column offsets for the three source columns. */
   const int nx = p->nx, ny = p->ny;
   for (int y = 0; y < ny; y++) {
-    int ysrc[3]; /* index by cy+1: source row for cy = -1, 0, +1 */
-    ysrc[0] = (y + 1) % ny;               /* cy = -1 pulls from the north row */
-    ysrc[1] = y;
-    ysrc[2] = (y == 0) ? ny - 1 : y - 1;  /* cy = +1 pulls from the south row */
+    const float* row_n = cells + (size_t)Q * nx * ((y + 1) % ny);          /* cy = -1 pulls from the north */
+    const float* row_c = cells + (size_t)Q * nx * y;
+    const float* row_s = cells + (size_t)Q * nx * ((y == 0) ? ny - 1 : y - 1); /* cy = +1 from the south */
+    float* out = tmp_cells + (size_t)Q * nx * y;
     for (int x = 0; x < nx; x++) {
-      int xsrc[3];
-      xsrc[0] = (x + 1) % nx;
-      xsrc[1] = x;
-      xsrc[2] = (x == 0) ? nx - 1 : x - 1;
-      float* out = tmp_cells + Q * ((size_t)y * nx + x);
-      for (int k = 0; k < Q; k++) {
-        const size_t s = (size_t)ysrc[CY[k] + 1] * nx + xsrc[CX[k] + 1];
-        out[k] = cells[Q * s + k];
-      }
+      const size_t e = (size_t)Q * ((x + 1) % nx);            /* cx = -1 pulls from the east cell */
+      const size_t c = (size_t)Q * x;
+      const size_t w = (size_t)Q * ((x == 0) ? nx - 1 : x - 1); /* cx = +1 from the west cell */
+      float* o = out + c;
+      o[0] = row_c[c + 0];
+      o[1] = row_c[w + 1];
+      o[2] = row_s[c + 2];
+      o[3] = row_c[e + 3];
+      o[4] = row_n[c + 4];
+      o[5] = row_s[w + 5];
+      o[6] = row_s[e + 6];
+      o[7] = row_n[e + 7];
+      o[8] = row_n[w + 8];
     }
   }
 }
