@@ -190,6 +190,43 @@ def test_two_steps_per_pass_random_lattice(lbm, oracle, monkeypatch):
         np.testing.assert_allclose(got_av, ref_av, rtol=AV_RTOL)
 
 
+def test_randomised_configurations_bitwise(lbm, oracle, monkeypatch):
+    """Seeded sweep over grid shapes, slab counts, band heights, kernels and step counts (random
+    populations and obstacles, both wraps live): every configuration must reproduce the oracle's
+    lattice bit for bit."""
+    rng = np.random.default_rng(20260101)
+    monkeypatch.setenv("LBM_HALO", "memcpy")
+    checked = 0
+    for case in range(60):
+        nx = int(rng.choice([4, 8, 12, 64, 100, 128, 252, 256, 260, 512, 1000]))
+        ny = int(rng.integers(8, 70))
+        slabs = int(rng.choice([1, 1, 2, 3, 4, 5]))
+        if ny // slabs < 4:
+            slabs = 1
+        fuse = int(rng.integers(0, 2))
+        band = int(rng.choice([2, 3, 4, 7, 8, 16]))
+        steps = int(rng.integers(1, 14))
+        monkeypatch.setenv("LBM_FUSE2", str(fuse))
+        monkeypatch.setenv("LBM_BAND_ROWS", str(band))
+        p, ob, cells = random_case(lbm, nx, ny, 1000 + case, blocked_frac=float(rng.choice([0.0, 0.03, 0.3])),
+                                   walls=bool(rng.integers(0, 2)))
+        ref_cells, ref_av, got_cells, got_av, _ = run_both(lbm, oracle, p, ob, cells, steps, n_gpus=slabs)
+        tag = dict(nx=nx, ny=ny, slabs=slabs, fuse=fuse, band=band, steps=steps)
+        assert np.array_equal(ref_cells.view(np.uint32), got_cells.view(np.uint32)), tag
+        np.testing.assert_allclose(got_av, ref_av, rtol=AV_RTOL, atol=1e-12, err_msg=str(tag))
+        checked += 1
+    assert checked == 60
+    # a few wider / taller ones: several strips per row, many bands per slab, uneven slabs
+    for nx, ny, slabs, band, steps in ((4096, 131, 3, 8, 9), (8192, 40, 2, 5, 6), (2048, 517, 4, 12, 5),
+                                       (1536, 260, 1, 23, 7)):
+        monkeypatch.setenv("LBM_FUSE2", "1")
+        monkeypatch.setenv("LBM_BAND_ROWS", str(band))
+        p, ob, cells = random_case(lbm, nx, ny, nx + ny, blocked_frac=0.02, walls=False)
+        ref_cells, ref_av, got_cells, got_av, _ = run_both(lbm, oracle, p, ob, cells, steps, n_gpus=slabs)
+        assert np.array_equal(ref_cells.view(np.uint32), got_cells.view(np.uint32)), (nx, ny, slabs, band)
+        np.testing.assert_allclose(got_av, ref_av, rtol=AV_RTOL)
+
+
 def test_rank_api_single_rank_rccl(lbm, oracle, datasets, monkeypatch):
     """lbm_create_rank with a world of one: ncclCommInitRank, halo send/recv to itself and the
     av_vels all-reduce all run through RCCL -- the code path every rank of a torchrun job takes."""
