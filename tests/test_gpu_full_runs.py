@@ -61,6 +61,21 @@ def test_cli_full_run_matches_serialcode_bytes_and_goldens(lbm, tmp_path, name):
         assert lbm.check_passes(gold[f"pressure_{name}"], pr)
 
 
+@pytest.mark.parametrize("name,gpus,fuse", [("128x256", "4", "0"), ("256x256", "3", "1"), ("1024x1024", "8", "1")])
+def test_cli_multi_slab_full_run_matches_serialcode_bytes(lbm, tmp_path, name, gpus, fuse):
+    """The command line with LBM_GPUS row slabs (here sharing the one device, halos by device copies):
+    final_state.dat is still the reference program's, byte for byte, at full iteration counts."""
+    pf = os.path.join(GOLDEN, "inputs", f"input_{name}.params")
+    of = os.path.join(GOLDEN, "inputs", f"obstacles_{name}.dat")
+    env = dict(os.environ, LBM_GPUS=gpus, LBM_HALO="memcpy", LBM_FUSE2=fuse)
+    out = subprocess.run([lbm.CLI_PATH, pf, of], cwd=tmp_path, capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stderr
+    ref = np.load(os.path.join(GOLDEN, f"serialcode_{name}.npz"))
+    assert md5(tmp_path / "final_state.dat") == str(ref["md5_final_state"])
+    av = np.loadtxt(tmp_path / "av_vels.dat", usecols=[1])
+    np.testing.assert_allclose(av, ref["av_vels"].astype(np.float64), rtol=5e-4)
+
+
 @pytest.mark.parametrize("name", ["128x128", "128x256", "256x256", "1024x1024"])
 @pytest.mark.parametrize("fuse", ["0", "1"])
 def test_fast_mode_full_run_passes_check_rule(lbm, datasets, golden, monkeypatch, name, fuse):
