@@ -117,6 +117,7 @@ struct lbm_ctx {
   int snake = 0;  // alternate the sweep direction every step (LBM_SNAKE overrides)
   int fuse2 = 0;  // two timesteps per pass (step2_stream) when a single periodic slab allows it
   int band_rows = 8, n_strips = 0;  // step2_stream geometry: band height, waves across x
+  int lane_cells = 4;               // cells per lane in step2_stream (4 or 2; LBM_LANE_CELLS)
 };
 
 namespace {
@@ -199,14 +200,14 @@ int launch_step2(lbm_ctx* c, int s, hipStream_t stream, int row_first, int row_e
   a.partials2 = a.partials1 + c->part_stride;
   const int waves = c->n_strips * band_count;
   typedef void (*fn)(const lbm::Step2Args);
+  // [math][nontemporal stores][cells per lane: 0 -> 4, 1 -> 2]
   static const fn table[2][2][2] = {
-      {{lbm::step2_stream<0, false, false>, lbm::step2_stream<0, false, true>},
-       {lbm::step2_stream<0, true, false>, lbm::step2_stream<0, true, true>}},
-      {{lbm::step2_stream<1, false, false>, lbm::step2_stream<1, false, true>},
-       {lbm::step2_stream<1, true, false>, lbm::step2_stream<1, true, true>}}};
-  static const int prefetch = env_int("LBM_PREFETCH", 0) ? 1 : 0;
-  hipLaunchKernelGGL(table[c->math_mode == LBM_MATH_EXACT ? 0 : 1][c->nts][prefetch], dim3(waves), dim3(64), 0,
-                     stream, a);
+      {{lbm::step2_stream<0, false, 4>, lbm::step2_stream<0, false, 2>},
+       {lbm::step2_stream<0, true, 4>, lbm::step2_stream<0, true, 2>}},
+      {{lbm::step2_stream<1, false, 4>, lbm::step2_stream<1, false, 2>},
+       {lbm::step2_stream<1, true, 4>, lbm::step2_stream<1, true, 2>}}};
+  hipLaunchKernelGGL(table[c->math_mode == LBM_MATH_EXACT ? 0 : 1][c->nts][c->lane_cells == 2 ? 1 : 0], dim3(waves),
+                     dim3(64), 0, stream, a);
   HIP_TRY(LBM_FAILURE, hipGetLastError());
   return LBM_SUCCESS;
 }
@@ -620,40 +621,48 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
     if (sl.blocks_main + sl.blocks_boundary > max_blocks) max_blocks = sl.blocks_main + sl.blocks_boundary;
   }
   // two-steps-per-pass geometry (single periodic slab only)
-  c->n_strips = ceil_div(params->nx / 4 > 0 ? params->nx / 4 : 1, lbm::kStripQuads);
-  // Band height of the two-step kernel.  A wave sweeps band_rows + 2 rows; 256 CUs x 12 waves
-  // (3 per SIMD at 138 VGPRs) are resident at once.  Big slabs run many rounds of waves and like
-  // short bands (8: measured best at 8192^2 and 4096^2).  A slab that fits in a few rounds is
-  // quantised by them: pick the height that fills k rounds exactly (measured on 8192x1024:
-  // 12 rows = 0.95 rounds 76.7 us, 11 rows = 1.04 rounds 87.7 us; profiles/r01_tuning.md).
+  // ---- which kernel, and its geometry (all measured on MI355X; profiles/r01_tuning.md) --------
+  //   slab <  2 Mi cells : one timestep per pass (step_vec4); the grid is cache resident and one
+  //                        resident wave of workgroups covers it (1024^2: 14.1 us vs 15.1+ two-step)
+  //   2 Mi .. 6 Mi cells : two timesteps per pass, 2 cells per lane (93 VGPRs, 5 waves/SIMD: twice the
+  //                        waves of the 4-cell form; 2048^2: 44.5 us vs 47.7 (4-cell) vs 54.9 (one-step))
+  //   >= 6 Mi cells      : two timesteps per pass, 4 cells per lane (16-byte accesses; 8192^2: 517 us vs
+  //                        575 (2-cell) vs 802 (one-step))
+  // LBM_FUSE2, LBM_LANE_CELLS, LBM_BAND_ROWS override.  Ranks decide from global numbers only, so
+  // every rank of a multi-process run takes the same path.
+  long min_cells = (long)params->nx * params->ny;
+  for (int s = 0; s < n_slabs; s++)
+    if ((long)params->nx * c->slab[s].rows < min_cells) min_cells = (long)params->nx * c->slab[s].rows;
+  if (world > 1) min_cells = (long)params->nx * (params->ny / world);
+  c->fuse2 = (c->vec4 && env_int("LBM_FUSE2", min_cells >= 2L * 1024 * 1024 ? 1 : 0)) ? 1 : 0;
+  c->lane_cells = env_int("LBM_LANE_CELLS", min_cells >= 6L * 1024 * 1024 ? 4 : 2) == 2 ? 2 : 4;
+  c->n_strips = ceil_div(params->nx / c->lane_cells > 0 ? params->nx / c->lane_cells : 1, lbm::kStripQuads);
+  // Band height.  A wave sweeps band_rows + 2 rows.  4-cell form: 256 CUs x 12 waves are resident
+  // at once; big slabs run many rounds of waves and like short bands (8: measured best at 8192^2
+  // and 4096^2), a slab that fits in a few rounds is quantised by them -- pick the height that
+  // fills k rounds exactly (8192x1024: 12 rows = 0.95 rounds 76.7 us, 11 rows = 1.04 rounds
+  // 87.7 us).  2-cell form (mid-size grids): 8 rows measured best or within 3 % (1536^2 .. 2048^2).
   {
-    const long resident = 256L * 12;
-    const long slab_rows = (n_slabs > 1 || world > 1) ? (c->row_count / n_slabs) - 4 : c->row_count;
-    const long rows_eff = slab_rows > 1 ? slab_rows : 1;
     int pick = 8;
-    if ((long)c->n_strips * ceil_div(rows_eff, 8) < 5 * resident) {
-      long best_cost = -1;
-      for (int k = 1; k <= 4; k++) {
-        long b = (rows_eff * c->n_strips + k * resident - 1) / (k * resident);
-        if (b < 4) b = 4;
-        if (b > 32) b = 32;
-        const long rounds = ((long)c->n_strips * ceil_div(rows_eff, b) + resident - 1) / resident;
-        const long cost = rounds * (b + 2);
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; pick = (int)b; }
+    if (c->lane_cells == 4) {
+      const long resident = 256L * 12;
+      const long slab_rows = (n_slabs > 1 || world > 1) ? (c->row_count / n_slabs) - 4 : c->row_count;
+      const long rows_eff = slab_rows > 1 ? slab_rows : 1;
+      if ((long)c->n_strips * ceil_div(rows_eff, 8) < 5 * resident) {
+        long best_cost = -1;
+        for (int k = 1; k <= 4; k++) {
+          long b = (rows_eff * c->n_strips + k * resident - 1) / (k * resident);
+          if (b < 4) b = 4;
+          if (b > 32) b = 32;
+          const long rounds = ((long)c->n_strips * ceil_div(rows_eff, b) + resident - 1) / resident;
+          const long cost = rounds * (b + 2);
+          if (best_cost < 0 || cost < best_cost) { best_cost = cost; pick = (int)b; }
+        }
       }
     }
     c->band_rows = env_int("LBM_BAND_ROWS", pick);
   }
   if (c->band_rows < 1) c->band_rows = 1;
-  // Two timesteps per pass pay once the slab is big enough to be HBM-bound (measured: 8192x1024 and
-  // 4096^2 win, 2048^2 ties, 1024^2 loses; profiles/r01_tuning.md).  LBM_FUSE2=0/1 overrides.
-  {
-    long min_cells = (long)params->nx * params->ny;
-    for (int s = 0; s < n_slabs; s++)
-      if ((long)params->nx * c->slab[s].rows < min_cells) min_cells = (long)params->nx * c->slab[s].rows;
-    if (world > 1) min_cells = (long)params->nx * (params->ny / world);  // every rank must decide alike
-    c->fuse2 = (c->vec4 && env_int("LBM_FUSE2", min_cells >= 6L * 1024 * 1024 ? 1 : 0)) ? 1 : 0;
-  }
   for (int s = 0; s < n_slabs; s++) {
     // across slabs the two-step kernel needs slabs of at least 4 rows
     if (c->halo != HALO_SELF && c->slab[s].rows < 4) c->fuse2 = 0;

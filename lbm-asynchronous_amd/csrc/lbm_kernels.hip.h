@@ -434,7 +434,7 @@ struct Step2Args {
   float* partials2;  // per wave: sum |u| after step t+1
 };
 
-constexpr int kStripQuads = 62;  // output quads per wave (lanes 1..62)
+constexpr int kStripQuads = 62;  // output lanes per wave (lanes 1..62; each owns C cells)
 
 template <int MATH>
 __device__ __forceinline__ void relax_cell(const float (&t)[kQ], bool blocked, bool lid, float omega, float a1,
@@ -449,30 +449,37 @@ __device__ __forceinline__ void relax_cell(const float (&t)[kQ], bool blocked, b
   }
 }
 
-// the 9 aligned vectors, 6 neighbour dwords and mask bytes one lane pulls for one row
+// the 9 aligned vectors and the mask bytes one lane pulls for one row; C cells per lane
+template <int C>
 struct RowPull {
-  float4 v0, v1, v2, v3, v4, v5, v6, v7, v8;
-  uchar4 m;
+  typedef float vec __attribute__((ext_vector_type(C)));
+  vec v[kQ];
+  unsigned m;  // C mask bytes
 };
 
-__device__ __forceinline__ RowPull pull_row(const Step2Args& a, int r, int x0) {
+template <int C>
+__device__ __forceinline__ RowPull<C> pull_row(const Step2Args& a, int r, int x0) {
+  typedef typename RowPull<C>::vec vec;
   const long ps = a.plane_stride;
   const int rs = (r == 0 && a.wrap) ? a.rows - 1 : r - 1;
   const int rn = (r == a.rows - 1 && a.wrap) ? 0 : r + 1;
-  const float* c_row = a.src + (long)r * a.row_pitch;
-  const float* sb = a.src + (long)rs * a.row_pitch;
-  const float* nb = a.src + (long)rn * a.row_pitch;
-  RowPull p;
-  p.v0 = *reinterpret_cast<const float4*>(c_row + x0);
-  p.v1 = *reinterpret_cast<const float4*>(c_row + 1 * ps + x0);
-  p.v3 = *reinterpret_cast<const float4*>(c_row + 3 * ps + x0);
-  p.v2 = *reinterpret_cast<const float4*>(sb + 2 * ps + x0);
-  p.v5 = *reinterpret_cast<const float4*>(sb + 5 * ps + x0);
-  p.v6 = *reinterpret_cast<const float4*>(sb + 6 * ps + x0);
-  p.v4 = *reinterpret_cast<const float4*>(nb + 4 * ps + x0);
-  p.v7 = *reinterpret_cast<const float4*>(nb + 7 * ps + x0);
-  p.v8 = *reinterpret_cast<const float4*>(nb + 8 * ps + x0);
-  p.m = *reinterpret_cast<const uchar4*>(a.mask + (long)r * a.pitch + x0);
+  const float* c_row = a.src + (long)r * a.row_pitch + x0;
+  const float* sb = a.src + (long)rs * a.row_pitch + x0;
+  const float* nb = a.src + (long)rn * a.row_pitch + x0;
+  RowPull<C> p;
+  p.v[0] = *reinterpret_cast<const vec*>(c_row);
+  p.v[1] = *reinterpret_cast<const vec*>(c_row + 1 * ps);
+  p.v[3] = *reinterpret_cast<const vec*>(c_row + 3 * ps);
+  p.v[2] = *reinterpret_cast<const vec*>(sb + 2 * ps);
+  p.v[5] = *reinterpret_cast<const vec*>(sb + 5 * ps);
+  p.v[6] = *reinterpret_cast<const vec*>(sb + 6 * ps);
+  p.v[4] = *reinterpret_cast<const vec*>(nb + 4 * ps);
+  p.v[7] = *reinterpret_cast<const vec*>(nb + 7 * ps);
+  p.v[8] = *reinterpret_cast<const vec*>(nb + 8 * ps);
+  const unsigned char* mp = a.mask + (long)r * a.pitch + x0;
+  if constexpr (C == 4) p.m = *reinterpret_cast<const unsigned*>(mp);
+  else if constexpr (C == 2) p.m = *reinterpret_cast<const unsigned short*>(mp);
+  else p.m = *mp;
   return p;
 }
 
@@ -485,108 +492,117 @@ __device__ __forceinline__ int wrap_row(int r, int rows, int wrap) {
   return r;
 }
 
-// PREFETCH: pull row r+1 before relaxing row r (one row of loads always in flight per wave;
-// +43 VGPRs).  Without it every iteration exposes a full memory round trip.
-template <int MATH, bool NTS, bool PREFETCH>
+// C = cells per lane (4: 16-byte accesses, 138 VGPRs, 3 waves/SIMD; 2: 8-byte accesses, about half
+// the registers, twice the waves -- better for slabs too small to fill the chip with 4-cell lanes)
+template <int MATH, bool NTS, int C>
 __global__ __launch_bounds__(64) void step2_stream(const Step2Args a) {
+  typedef typename RowPull<C>::vec vec;
   const int lane = threadIdx.x;
   const int strip = blockIdx.x % a.n_strips;
-  const int quads_x = a.nx >> 2;
+  const int units_x = a.nx / C;
   const int y0 = a.row_first + (int)(blockIdx.x / a.n_strips) * a.band_pitch;
   const int band_n = min(a.band_rows, a.row_end - y0);
 
-  // this lane's quad (may lie outside the grid: halo lanes and the tail of the last strip wrap)
-  const int qx_raw = strip * kStripQuads + lane - 1;
-  int qx = qx_raw % quads_x;
-  if (qx < 0) qx += quads_x;
-  const int x0 = qx << 2;
-  const bool out_lane = (lane >= 1) && (lane <= kStripQuads) && (qx_raw < quads_x);
+  // this lane's group of C cells (may lie outside the grid: halo lanes and the tail of the last
+  // strip wrap around)
+  const int ux_raw = strip * kStripQuads + lane - 1;
+  int ux = ux_raw % units_x;
+  if (ux < 0) ux += units_x;
+  const int x0 = ux * C;
+  const bool out_lane = (lane >= 1) && (lane <= kStripQuads) && (ux_raw < units_x);
   const long ps = a.plane_stride;
 
   // sliding window of step-t results (registers)
-  float w256[3][4];  // speeds 2,5,6 of row r-2
-  float w013[3][4];  // speeds 0,1,3 of row r-1
-  float n256[3][4];  // speeds 2,5,6 of row r-1 (become w256 after the rotation)
-  uchar4 m_prev = make_uchar4(0, 0, 0, 0);
+  float w256[3][C];  // speeds 2,5,6 of row r-2
+  float w013[3][C];  // speeds 0,1,3 of row r-1
+  float n256[3][C];  // speeds 2,5,6 of row r-1 (become w256 after the rotation)
+  unsigned m_prev = 0;
   float sum1 = 0.f, sum2 = 0.f;
-
-  RowPull nxt;
-  if constexpr (PREFETCH) nxt = pull_row(a, wrap_row(y0 - 1, a.rows, a.wrap), x0);
 
   for (int i = 0; i < band_n + 2; i++) {
     // ---- step t on row r ------------------------------------------------------------------
     const int r = wrap_row(y0 - 1 + i, a.rows, a.wrap);
-    RowPull p;
-    if constexpr (PREFETCH) {
-      p = nxt;
-      if (i + 1 < band_n + 2) nxt = pull_row(a, wrap_row(y0 + i, a.rows, a.wrap), x0);
-    } else {
-      p = pull_row(a, r, x0);
-    }
+    const RowPull<C> p = pull_row<C>(a, r, x0);
     // +-1 column neighbours of the pulled vectors come from the adjacent lanes.  Lane 0 has no
     // west lane and lane 63 no east lane: their outermost cells get zeros and produce garbage,
-    // which nothing consumes (those lanes are halo quads; only their inner edge feeds a neighbour).
-    const float e1 = lane_from_west<2>(p.v1.w), e5 = lane_from_west<2>(p.v5.w), e8 = lane_from_west<2>(p.v8.w);
-    const float e3 = lane_from_east<2>(p.v3.x), e6 = lane_from_east<2>(p.v6.x), e7 = lane_from_east<2>(p.v7.x);
+    // which nothing consumes (those lanes are halo groups; only their inner edge feeds a neighbour).
+    const float e1 = lane_from_west<2>(p.v[1][C - 1]), e5 = lane_from_west<2>(p.v[5][C - 1]),
+                e8 = lane_from_west<2>(p.v[8][C - 1]);
+    const float e3 = lane_from_east<2>(p.v[3][0]), e6 = lane_from_east<2>(p.v[6][0]),
+                e7 = lane_from_east<2>(p.v[7][0]);
 
-    float t[4][kQ] = {
-        {p.v0.x, e1,     p.v2.x, p.v3.y, p.v4.x, e5,     p.v6.y, p.v7.y, e8},
-        {p.v0.y, p.v1.x, p.v2.y, p.v3.z, p.v4.y, p.v5.x, p.v6.z, p.v7.z, p.v8.x},
-        {p.v0.z, p.v1.y, p.v2.z, p.v3.w, p.v4.z, p.v5.y, p.v6.w, p.v7.w, p.v8.y},
-        {p.v0.w, p.v1.z, p.v2.w, e3,     p.v4.w, p.v5.z, e6,     e7,     p.v8.z}};
-    const unsigned char blk[4] = {p.m.x, p.m.y, p.m.z, p.m.w};
+    float t[C][kQ];
+#pragma unroll
+    for (int j = 0; j < C; j++) {
+      const int jw = (j == 0) ? 0 : j - 1, je = (j == C - 1) ? C - 1 : j + 1;
+      t[j][0] = p.v[0][j];
+      t[j][1] = (j == 0) ? e1 : p.v[1][jw];
+      t[j][2] = p.v[2][j];
+      t[j][3] = (j == C - 1) ? e3 : p.v[3][je];
+      t[j][4] = p.v[4][j];
+      t[j][5] = (j == 0) ? e5 : p.v[5][jw];
+      t[j][6] = (j == C - 1) ? e6 : p.v[6][je];
+      t[j][7] = (j == C - 1) ? e7 : p.v[7][je];
+      t[j][8] = (j == 0) ? e8 : p.v[8][jw];
+    }
     const bool lid = (r == a.accel_row);
     const bool own_row = (i >= 1) && (i <= band_n);  // rows y0 .. y0+band_n-1 belong to this band
-    float N[4][kQ];
+    float N[C][kQ];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < C; j++) {
       float speed;
-      relax_cell<MATH>(t[j], blk[j] != 0, lid, a.omega, a.a1, a.a2, N[j], speed);
+      relax_cell<MATH>(t[j], ((p.m >> (8 * j)) & 0xffu) != 0, lid, a.omega, a.a1, a.a2, N[j], speed);
       if (own_row && out_lane) sum1 += speed;
     }
 
     // ---- step t+1 on row r-1 (needs step-t rows r-2, r-1, r) -------------------------------
     if (i >= 2) {
       const int ro = wrap_row(r - 1, a.rows, a.wrap);
-      // neighbours in x from the adjacent lanes: west cell = lane-1's 4th cell, east = lane+1's 1st
-      const float w1 = lane_from_west<2>(w013[1][3]);
-      const float w5 = lane_from_west<2>(w256[1][3]);
-      const float w8 = lane_from_west<2>(N[3][8]);
+      // neighbours in x from the adjacent lanes: west cell = lane-1's last cell, east = lane+1's first
+      const float w1 = lane_from_west<2>(w013[1][C - 1]);
+      const float w5 = lane_from_west<2>(w256[1][C - 1]);
+      const float w8 = lane_from_west<2>(N[C - 1][8]);
       const float x3 = lane_from_east<2>(w013[2][0]);
       const float x6 = lane_from_east<2>(w256[2][0]);
       const float x7 = lane_from_east<2>(N[0][7]);
-      float u[4][kQ];
+      float u[C][kQ];
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
+      for (int j = 0; j < C; j++) {
+        const int jw = (j == 0) ? 0 : j - 1, je = (j == C - 1) ? C - 1 : j + 1;
         u[j][0] = w013[0][j];
-        u[j][1] = (j == 0) ? w1 : w013[1][j == 0 ? 0 : j - 1];
+        u[j][1] = (j == 0) ? w1 : w013[1][jw];
         u[j][2] = w256[0][j];
-        u[j][3] = (j == 3) ? x3 : w013[2][j == 3 ? 3 : j + 1];
+        u[j][3] = (j == C - 1) ? x3 : w013[2][je];
         u[j][4] = N[j][4];
-        u[j][5] = (j == 0) ? w5 : w256[1][j == 0 ? 0 : j - 1];
-        u[j][6] = (j == 3) ? x6 : w256[2][j == 3 ? 3 : j + 1];
-        u[j][7] = (j == 3) ? x7 : N[j == 3 ? 3 : j + 1][7];
-        u[j][8] = (j == 0) ? w8 : N[j == 0 ? 0 : j - 1][8];
+        u[j][5] = (j == 0) ? w5 : w256[1][jw];
+        u[j][6] = (j == C - 1) ? x6 : w256[2][je];
+        u[j][7] = (j == C - 1) ? x7 : N[je][7];
+        u[j][8] = (j == 0) ? w8 : N[jw][8];
       }
-      const unsigned char pb[4] = {m_prev.x, m_prev.y, m_prev.z, m_prev.w};
       const bool lid2 = (ro == a.accel_row) && a.accel_after;
-      float R[4][kQ];
+      float R[C][kQ];
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
+      for (int j = 0; j < C; j++) {
         float speed;
-        relax_cell<MATH>(u[j], pb[j] != 0, lid2, a.omega, a.a1, a.a2, R[j], speed);
+        relax_cell<MATH>(u[j], ((m_prev >> (8 * j)) & 0xffu) != 0, lid2, a.omega, a.a1, a.a2, R[j], speed);
         if (out_lane) sum2 += speed;
       }
       if (out_lane) {
         float* d_row = a.dst + (long)ro * a.row_pitch + x0;
 #pragma unroll
-        for (int k = 0; k < kQ; k++) store4<NTS>(d_row + k * ps, R[0][k], R[1][k], R[2][k], R[3][k]);
+        for (int k = 0; k < kQ; k++) {
+          vec o;
+#pragma unroll
+          for (int j = 0; j < C; j++) o[j] = R[j][k];
+          if constexpr (NTS) __builtin_nontemporal_store(o, reinterpret_cast<vec*>(d_row + k * ps));
+          else *reinterpret_cast<vec*>(d_row + k * ps) = o;
+        }
       }
     }
 
     // ---- rotate the window ------------------------------------------------------------------
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < C; j++) {
       w256[0][j] = n256[0][j];  w256[1][j] = n256[1][j];  w256[2][j] = n256[2][j];
       n256[0][j] = N[j][2];     n256[1][j] = N[j][5];     n256[2][j] = N[j][6];
       w013[0][j] = N[j][0];     w013[1][j] = N[j][1];     w013[2][j] = N[j][3];

@@ -170,7 +170,7 @@ def test_cli_8192_tiled_run_against_oracle_cli(lbm, oracle, tmp_path):
     assert re_g == pytest.approx(re_c, rel=2e-3)
 
 
-def test_8192_two_kernels_agree_bitwise_after_1001_steps(lbm, big_case, monkeypatch):
+def test_8192_three_kernels_agree_bitwise_after_1001_steps(lbm, big_case, monkeypatch):
     """Size-independent cross-check at BASELINE's full size: the one-step kernel and the
     two-steps-per-pass kernel are independent implementations of the same arithmetic (different
     data flow, different neighbour exchange); after 1001 steps on 8192x8192 (odd: the two-step run
@@ -179,19 +179,21 @@ def test_8192_two_kernels_agree_bitwise_after_1001_steps(lbm, big_case, monkeypa
     p0, ob = big_case
     p = lbm.Params(p0.nx, p0.ny, 1001, p0.reynolds_dim, p0.density, p0.accel, p0.omega)
     out = {}
-    for fuse in ("0", "1"):
+    for fuse, lane_cells in (("0", "4"), ("1", "4"), ("1", "2")):
         monkeypatch.setenv("LBM_FUSE2", fuse)
+        monkeypatch.setenv("LBM_LANE_CELLS", lane_cells)
         with lbm.Engine(p, ob, None) as eng:
             assert eng.info()["steps_per_launch"] == (2 if fuse == "1" else 1)
             m0 = eng.total_density()
             eng.run(1001)
             assert eng.total_density() == pytest.approx(m0, rel=1e-6)
             f = eng.final_state()
-            out[fuse] = (f["pressure"].copy(), f["u"].copy(), eng.av_vels(1001))
-    assert np.array_equal(out["0"][0].view(np.uint32), out["1"][0].view(np.uint32))
-    assert np.array_equal(out["0"][1].view(np.uint32), out["1"][1].view(np.uint32))
-    np.testing.assert_allclose(out["0"][2], out["1"][2], rtol=1e-6)
-    assert np.isfinite(out["1"][2]).all() and out["1"][2][-1] > out["1"][2][0] > 0
+            out[fuse + lane_cells] = (f["pressure"].copy(), f["u"].copy(), eng.av_vels(1001))
+    for other in ("14", "12"):      # two-step kernel with 4 and with 2 cells per lane
+        assert np.array_equal(out["04"][0].view(np.uint32), out[other][0].view(np.uint32))
+        assert np.array_equal(out["04"][1].view(np.uint32), out[other][1].view(np.uint32))
+        np.testing.assert_allclose(out["04"][2], out[other][2], rtol=1e-6)
+    assert np.isfinite(out["14"][2]).all() and out["14"][2][-1] > out["14"][2][0] > 0
 
 
 def test_8192_properties(lbm, big_case):

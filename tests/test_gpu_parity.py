@@ -156,14 +156,15 @@ def test_rccl_self_exchange(lbm, oracle, datasets, monkeypatch):
     np.testing.assert_allclose(got_av, ref_av, rtol=AV_RTOL)
 
 
-@pytest.mark.parametrize("band", [2, 5, 8, 64])
+@pytest.mark.parametrize("band,lane_cells", [(2, 4), (5, 2), (8, 4), (8, 2), (64, 4), (3, 2)])
 @pytest.mark.parametrize("slabs,halo", [(1, None), (1, "rccl"), (2, "memcpy"), (3, "memcpy"), (8, "memcpy")])
-def test_two_steps_per_pass_kernel_bitwise(lbm, oracle, datasets, monkeypatch, band, slabs, halo):
+def test_two_steps_per_pass_kernel_bitwise(lbm, oracle, datasets, monkeypatch, band, lane_cells, slabs, halo):
     """The two-timesteps-per-pass kernel (step2_stream: register sliding window, DPP neighbours,
     2-row halos across slabs) is forced on at test sizes; odd step counts end with a one-step launch.
     Same per-cell arithmetic, so the lattice stays bit-identical to the oracle."""
     monkeypatch.setenv("LBM_FUSE2", "1")
     monkeypatch.setenv("LBM_BAND_ROWS", str(band))
+    monkeypatch.setenv("LBM_LANE_CELLS", str(lane_cells))      # 4 or 2 cells per lane
     if halo:
         monkeypatch.setenv("LBM_HALO", halo)
         if slabs == 1:
@@ -184,6 +185,7 @@ def test_two_steps_per_pass_random_lattice(lbm, oracle, monkeypatch):
     monkeypatch.setenv("LBM_BAND_ROWS", "3")
     monkeypatch.setenv("LBM_HALO", "memcpy")
     for nx, ny, slabs in ((256, 24, 1), (512, 23, 4), (64, 40, 5), (1024, 9, 2)):
+        monkeypatch.setenv("LBM_LANE_CELLS", "4" if ny % 2 else "2")
         p, ob, cells = random_case(lbm, nx, ny, 100 + ny, walls=False)
         ref_cells, ref_av, got_cells, got_av, _ = run_both(lbm, oracle, p, ob, cells, 20, n_gpus=slabs)
         assert np.array_equal(ref_cells.view(np.uint32), got_cells.view(np.uint32)), (nx, ny, slabs)
@@ -206,21 +208,24 @@ def test_randomised_configurations_bitwise(lbm, oracle, monkeypatch):
         fuse = int(rng.integers(0, 2))
         band = int(rng.choice([2, 3, 4, 7, 8, 16]))
         steps = int(rng.integers(1, 14))
+        lane_cells = int(rng.choice([2, 4]))
         monkeypatch.setenv("LBM_FUSE2", str(fuse))
         monkeypatch.setenv("LBM_BAND_ROWS", str(band))
+        monkeypatch.setenv("LBM_LANE_CELLS", str(lane_cells))
         p, ob, cells = random_case(lbm, nx, ny, 1000 + case, blocked_frac=float(rng.choice([0.0, 0.03, 0.3])),
                                    walls=bool(rng.integers(0, 2)))
         ref_cells, ref_av, got_cells, got_av, _ = run_both(lbm, oracle, p, ob, cells, steps, n_gpus=slabs)
-        tag = dict(nx=nx, ny=ny, slabs=slabs, fuse=fuse, band=band, steps=steps)
+        tag = dict(nx=nx, ny=ny, slabs=slabs, fuse=fuse, band=band, lane_cells=lane_cells, steps=steps)
         assert np.array_equal(ref_cells.view(np.uint32), got_cells.view(np.uint32)), tag
         np.testing.assert_allclose(got_av, ref_av, rtol=AV_RTOL, atol=1e-12, err_msg=str(tag))
         checked += 1
     assert checked == 60
     # a few wider / taller ones: several strips per row, many bands per slab, uneven slabs
-    for nx, ny, slabs, band, steps in ((4096, 131, 3, 8, 9), (8192, 40, 2, 5, 6), (2048, 517, 4, 12, 5),
-                                       (1536, 260, 1, 23, 7)):
+    for nx, ny, slabs, band, steps, lane_cells in ((4096, 131, 3, 8, 9, 4), (8192, 40, 2, 5, 6, 2),
+                                                   (2048, 517, 4, 12, 5, 2), (1536, 260, 1, 23, 7, 4)):
         monkeypatch.setenv("LBM_FUSE2", "1")
         monkeypatch.setenv("LBM_BAND_ROWS", str(band))
+        monkeypatch.setenv("LBM_LANE_CELLS", str(lane_cells))
         p, ob, cells = random_case(lbm, nx, ny, nx + ny, blocked_frac=0.02, walls=False)
         ref_cells, ref_av, got_cells, got_av, _ = run_both(lbm, oracle, p, ob, cells, steps, n_gpus=slabs)
         assert np.array_equal(ref_cells.view(np.uint32), got_cells.view(np.uint32)), (nx, ny, slabs, band)
