@@ -14,7 +14,7 @@ the builder container and the 1-GPU box lack, so this test replays the SAME prot
   * two-step pass: step t is relaxed on rows -1..rows (the two halo-adjacent rows redundantly,
     exactly as the neighbour relaxes them), step t+1 on the owned rows; the lid row (global ny-2)
     is accelerated wherever a rank holds a copy of it, owned or halo;
-  * an odd step count ends with a one-step pass (halo depth 1);
+  * an odd step count ends with a one-step pass (which reads only the inner halo row);
   * per-step partial sums of |u| over OWNED rows all-reduced at the end
     (MPI/d2q9-bgk.c:298-309) and divided by the global fluid-cell count; rows gathered on rank 0
     (MPI/d2q9-bgk.c:265-295).
@@ -99,7 +99,7 @@ def rank_main(rank, world, port, name, steps, out_dir):
         t = 0
         while t < steps:
             two = t + 1 < steps
-            depth = 2 if two else 1
+            depth = 2          # the engine ships both halo rows every pass once the two-step kernel is on
             # accelerate_flow of step t on the owned copy; the halo copies arrive already accelerated
             if lid_local is not None and 0 <= lid_local < rows:
                 accelerate(S, lid_local)
