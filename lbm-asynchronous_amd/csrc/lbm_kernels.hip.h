@@ -85,20 +85,22 @@ __device__ __forceinline__ void moments_exact(const float (&f)[kQ], float& rho, 
 //     q = x*R;  r = fma(-C, q, x);  q' = fma(r, R, q)
 // q' equals the correctly rounded x / C -- verified EXHAUSTIVELY on the CPU for every fp32 x with
 // 1e-30 < |x| < 1e30 and each of the three constants (tools/verify_const_div.c; the only
-// mismatches lie where the residual r underflows or x*R overflows).  x = 0 gives 0.  Outside that
-// range the kernel takes the IEEE divide, so the result is bit-identical to the reference's
-// "x / c_sq" for ALL inputs at 3 instructions instead of ~11 plus a quarter-rate v_rcp_f32.
+// mismatches lie where the residual r underflows or x*R overflows); x = 0 gives 0.
+// Below 1e-30 the fast quotient may be a few ulps off, but it cannot change the result: every
+// quotient is only ever ADDED to a value that is exactly 1 at that point --
+//   eq_k = w*rho * (((1 + u_k/c^2) + u_k^2/(2c^4)) - |u|^2/(2c^2)):
+//   |u_k^2| < 1e-30 means |u_k| < 1e-15, so |u_k/c^2| < 2^-25 and 1 + u_k/c^2 == 1, then
+//   1 + (anything below 2^-25) == 1;  |u|^2 < 1e-30 means every |u_k| < 2e-15, so the minuend is 1
+//   and 1 - (anything below 2^-25) == 1
+// -- and a wrong-by-ulps number below 5e-30 is absorbed exactly like the right one (also checked
+// exhaustively: the fast quotient of every |x| <= 1e-30 is finite and below 2^-90).
+// Only huge dividends need care: a cell whose |u|^2 is not below 5e28 (or is NaN) takes the IEEE
+// divides.  So the result is bit-identical to the reference's "x / c_sq" for ALL inputs at
+// 3 instructions per divide instead of ~11 plus a quarter-rate v_rcp_f32.
 __device__ __forceinline__ float div_const_fast(float x, float C, float R) {
   const float q = x * R;
   const float r = __fmaf_rn(-C, q, x);
   return __fmaf_rn(r, R, q);
-}
-// u is a safe dividend for the fast form, and so is u*u: u == 0, or 1e-30 < u*u < 1e29
-// (then 1e-15 < |u| < 3.2e14).  The range test is one integer subtract + unsigned compare on the
-// bits of the non-negative square.  A non-zero u whose square underflows to 0 fails the test.
-__device__ __forceinline__ int fast_div_ok(float u) {
-  const unsigned b = __float_as_uint(u * u);
-  return (int)(u == 0.f) | (int)((b - 0x0DA24261u) < (0x6FA18F08u - 0x0DA24261u));
 }
 
 struct EqTerms {
@@ -160,9 +162,9 @@ __device__ __forceinline__ void collide<true>(const float (&t)[kQ], float omega,
                                               float& speed) {
   float rho, ux, uy;
   moments_exact(t, rho, ux, uy);
-  // the fast constant divides are exact when every dividend is 0 or of ordinary magnitude; the
-  // squares are the smallest non-zero dividends, and (u == 0 or u*u in range) also bounds u itself
-  const int ok = fast_div_ok(ux) & fast_div_ok(uy) & fast_div_ok(ux + uy) & fast_div_ok(-ux + uy);
+  // |u|^2 below 5e28 bounds every dividend of the fast constant divides (squares of ux, uy,
+  // ux+-uy are at most 2|u|^2 < 1e29); NaN compares false and takes the IEEE path
+  const bool ok = (ux * ux + uy * uy) < 5.0e28f;
   if (ok) collide_exact_body<true>(t, omega, rho, ux, uy, r);
   else    collide_exact_body<false>(t, omega, rho, ux, uy, r);
   // av_velocity() looks at the relaxed populations (SerialCode/d2q9-bgk.c:169, 426-450)

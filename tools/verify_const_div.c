@@ -27,6 +27,17 @@ int main(void){
       if (ubits(q1)!=ubits(want)) { bad3++; float ax=fabsf(x); if (ax>1e-30f && ax<1e30f) bad3_norm++; }
       if (ubits(q2)!=ubits(want)) bad5++;
     }
+    /* tiny dividends: the fast quotient must stay finite and far below 2^-25 (it is then absorbed
+       by the additions to 1.f exactly like the correct quotient) */
+    long tiny_bad = 0;
+    #pragma omp parallel for reduction(+:tiny_bad) schedule(static)
+    for (int64_t i=0;i<(1LL<<32);i++){
+      uint32_t u=(uint32_t)i; float x=bits(u);
+      if (!isfinite(x) || fabsf(x) > 1e-30f) continue;
+      float q0 = x*R; float r0 = fmaf(-C,q0,x); float q1 = fmaf(r0,R,q0);
+      if (!isfinite(q1) || fabsf(q1) > 0x1p-90f) tiny_bad++;
+    }
+    printf("C=%.9g: dividends with |x| <= 1e-30 whose fast quotient is not finite and below 2^-90: %ld\n", C, tiny_bad);
     printf("C=%.9g (0x%08x) R=%.9g: 3-op mismatches %ld (in 1e-30<|x|<1e30: %ld), 5-op mismatches %ld\n", C, ubits(C), R, bad3, bad3_norm, bad5);
   }
   return 0;
