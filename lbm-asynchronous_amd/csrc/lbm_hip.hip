@@ -622,10 +622,10 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
   }
   // two-steps-per-pass geometry (single periodic slab only)
   // ---- which kernel, and its geometry (all measured on MI355X; profiles/r01_tuning.md) --------
-  //   slab <  2 Mi cells : one timestep per pass (step_vec4); the grid is cache resident and one
-  //                        resident wave of workgroups covers it (1024^2: 14.1 us vs 15.1+ two-step)
-  //   2 Mi .. 6 Mi cells : two timesteps per pass, 2 cells per lane (93 VGPRs, 5 waves/SIMD: twice the
-  //                        waves of the 4-cell form; 2048^2: 44.5 us vs 47.7 (4-cell) vs 54.9 (one-step))
+  //   slab < 1.5 Mi cells: one timestep per pass (step_vec4); the grid is cache resident and one
+  //                        resident wave of workgroups covers it (1024^2: 13.5 us vs 13.8+ two-step)
+  //   1.5 .. 6 Mi cells  : two timesteps per pass, 2 cells per lane (93 VGPRs, 5 waves/SIMD: twice the
+  //                        waves of the 4-cell form; 1280^2: 19.1 vs 21.2 us, 2048^2: 40 vs 51.5 (one-step))
   //   >= 6 Mi cells      : two timesteps per pass, 4 cells per lane (16-byte accesses; 8192^2: 517 us vs
   //                        575 (2-cell) vs 802 (one-step))
   // LBM_FUSE2, LBM_LANE_CELLS, LBM_BAND_ROWS override.  Ranks decide from global numbers only, so
@@ -634,30 +634,30 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
   for (int s = 0; s < n_slabs; s++)
     if ((long)params->nx * c->slab[s].rows < min_cells) min_cells = (long)params->nx * c->slab[s].rows;
   if (world > 1) min_cells = (long)params->nx * (params->ny / world);
-  c->fuse2 = (c->vec4 && env_int("LBM_FUSE2", min_cells >= 2L * 1024 * 1024 ? 1 : 0)) ? 1 : 0;
+  c->fuse2 = (c->vec4 && env_int("LBM_FUSE2", min_cells >= 3L * 512 * 1024 ? 1 : 0)) ? 1 : 0;
   c->lane_cells = env_int("LBM_LANE_CELLS", min_cells >= 6L * 1024 * 1024 ? 4 : 2) == 2 ? 2 : 4;
   c->n_strips = ceil_div(params->nx / c->lane_cells > 0 ? params->nx / c->lane_cells : 1, lbm::kStripQuads);
   // Band height.  A wave sweeps band_rows + 2 rows.  4-cell form: 256 CUs x 12 waves are resident
   // at once; big slabs run many rounds of waves and like short bands (8: measured best at 8192^2
   // and 4096^2), a slab that fits in a few rounds is quantised by them -- pick the height that
   // fills k rounds exactly (8192x1024: 12 rows = 0.95 rounds 76.7 us, 11 rows = 1.04 rounds
-  // 87.7 us).  2-cell form (mid-size grids): 8 rows measured best or within 3 % (1536^2 .. 2048^2).
+  // 87.7 us).  The 2-cell form (mid-size grids) keeps 256 x 20 waves resident; same rule
+  // (1536^2: 4 rows = 0.98 rounds 24.0 us, 8 rows 25.3 us).
   {
     int pick = 8;
-    if (c->lane_cells == 4) {
-      const long resident = 256L * 12;
-      const long slab_rows = (n_slabs > 1 || world > 1) ? (c->row_count / n_slabs) - 4 : c->row_count;
-      const long rows_eff = slab_rows > 1 ? slab_rows : 1;
-      if ((long)c->n_strips * ceil_div(rows_eff, 8) < 5 * resident) {
-        long best_cost = -1;
-        for (int k = 1; k <= 4; k++) {
-          long b = (rows_eff * c->n_strips + k * resident - 1) / (k * resident);
-          if (b < 4) b = 4;
-          if (b > 32) b = 32;
-          const long rounds = ((long)c->n_strips * ceil_div(rows_eff, b) + resident - 1) / resident;
-          const long cost = rounds * (b + 2);
-          if (best_cost < 0 || cost < best_cost) { best_cost = cost; pick = (int)b; }
-        }
+    const long resident = 256L * 4 * (c->lane_cells == 4 ? 3 : 5);  // waves resident at once
+    const long slab_rows = (n_slabs > 1 || world > 1) ? (c->row_count / n_slabs) - 4 : c->row_count;
+    const long rows_eff = slab_rows > 1 ? slab_rows : 1;
+    if ((long)c->n_strips * ceil_div(rows_eff, 8) < 5 * resident) {
+      const long lo = (c->lane_cells == 4) ? 4 : 3;
+      long best_cost = -1;
+      for (int k = 1; k <= 4; k++) {
+        long b = (rows_eff * c->n_strips + k * resident - 1) / (k * resident);
+        if (b < lo) b = lo;
+        if (b > 32) b = 32;
+        const long rounds = ((long)c->n_strips * ceil_div(rows_eff, b) + resident - 1) / resident;
+        const long cost = rounds * (b + 2);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; pick = (int)b; }
       }
     }
     c->band_rows = env_int("LBM_BAND_ROWS", pick);
