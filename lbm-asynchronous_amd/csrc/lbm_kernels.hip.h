@@ -157,11 +157,58 @@ __device__ __forceinline__ void collide_exact_body(const float (&t)[kQ], float o
 template <bool EXACT>
 __device__ __forceinline__ void collide(const float (&t)[kQ], float omega, float (&r)[kQ], float& speed);
 
+// ---- the two divides by the density, sharing one reciprocal -----------------------------------
+// hipcc expands the IEEE fp32 divide a / b (AMDGPU LowerFDIV32) into
+//     r0 = v_rcp_f32(b);  e = fma(-b, r0, 1);  r = fma(e, r0, r0);            (refined reciprocal)
+//     q = a*r;  e = fma(-b, q, a);  q = fma(e, r, q);  e = fma(-b, q, a);  q = fma(e, r, q)
+// wrapped in v_div_scale / v_div_fmas / v_div_fixup, which only act when an operand or the
+// quotient is near the ends of the exponent range (denominator denormal or above 2^126,
+// |a| below 2^-103, |a/b| above 2^96 or denormal) or is 0 / inf / NaN.  u_x and u_y divide by the
+// same density, so the first line is done once and the second per numerator: the very same
+// instructions, hence the same bits, 28 instead of 48 issue slots per cell.  Outside the plain
+// range: a density outside [2^-60, 2^60] sends the cell to the IEEE divides; a numerator of 0 gives 0
+// either way; a non-zero numerator below 2^-103 gives a quotient below 2^-43 that may differ in
+// its last bits -- before the collision such a u is absorbed like the tiny quotients above
+// (|u/c^2| < 2^-25), after it it only enters the diagnostic sum of |u| at the 1e-13 level; a
+// quotient above 2^96 trips the |u|^2 guard.
+__device__ __forceinline__ bool density_in_plain_range(float rho) {
+  return (__float_as_uint(rho) - 0x21800000u) < (0x5D800000u - 0x21800000u);  // 2^-60 <= rho < 2^60
+}
+__device__ __forceinline__ float refined_rcp(float b) {
+  const float r0 = __builtin_amdgcn_rcpf(b);
+  const float e = __fmaf_rn(-b, r0, 1.f);
+  return __fmaf_rn(e, r0, r0);
+}
+__device__ __forceinline__ float div_with_rcp(float a, float b, float r) {
+  float q = a * r;
+  float e = __fmaf_rn(-b, q, a);
+  q = __fmaf_rn(e, r, q);
+  e = __fmaf_rn(-b, q, a);
+  return __fmaf_rn(e, r, q);
+}
+// density and velocity as moments_exact; false when the density forced the IEEE divides
+__device__ __forceinline__ void moments_shared(const float (&f)[kQ], float& rho, float& ux, float& uy) {
+  float d = f[0];
+#pragma unroll
+  for (int k = 1; k < kQ; k++) d += f[k];
+  rho = d;
+  const float X = f[1] + f[5] + f[8] - (f[3] + f[6] + f[7]);
+  const float Y = f[2] + f[5] + f[6] - (f[4] + f[7] + f[8]);
+  if (density_in_plain_range(d)) {
+    const float r = refined_rcp(d);
+    ux = div_with_rcp(X, d, r);
+    uy = div_with_rcp(Y, d, r);
+  } else {
+    ux = X / d;
+    uy = Y / d;
+  }
+}
+
 template <>
 __device__ __forceinline__ void collide<true>(const float (&t)[kQ], float omega, float (&r)[kQ],
                                               float& speed) {
   float rho, ux, uy;
-  moments_exact(t, rho, ux, uy);
+  moments_shared(t, rho, ux, uy);
   // |u|^2 below 5e28 bounds every dividend of the fast constant divides (squares of ux, uy,
   // ux+-uy are at most 2|u|^2 < 1e29); NaN compares false and takes the IEEE path
   const bool ok = (ux * ux + uy * uy) < 5.0e28f;
@@ -169,7 +216,7 @@ __device__ __forceinline__ void collide<true>(const float (&t)[kQ], float omega,
   else    collide_exact_body<false>(t, omega, rho, ux, uy, r);
   // av_velocity() looks at the relaxed populations (SerialCode/d2q9-bgk.c:169, 426-450)
   float rho2, ux2, uy2;
-  moments_exact(r, rho2, ux2, uy2);
+  moments_shared(r, rho2, ux2, uy2);
   speed = sqrtf((ux2 * ux2) + (uy2 * uy2));  // IEEE: __fsqrt_rn is the native approximation
 }
 
