@@ -179,6 +179,24 @@ def test_two_steps_per_pass_kernel_bitwise(lbm, oracle, datasets, monkeypatch, b
     assert np.array_equal(ref_f["pressure"].view(np.uint32), fields["pressure"].view(np.uint32))
 
 
+def test_two_step_runs_in_pieces_across_slabs(lbm, oracle, datasets, monkeypatch):
+    """lbm_run in pieces of odd and even length with the two-step kernel on and three slabs
+    (default halo transport for slabs that share a device): every piece starts with its own
+    accelerate pass and halo exchange and may end with a one-step launch."""
+    monkeypatch.setenv("LBM_FUSE2", "1")
+    monkeypatch.delenv("LBM_HALO", raising=False)
+    p, ob = datasets("128x256")
+    cells = oracle.init_cells(p)
+    ref = cells.copy()
+    ref_av = oracle.run(p, ref, ob, 64)
+    with lbm.Engine(p, ob, cells, n_gpus=3) as eng:
+        for n in (1, 2, 3, 8, 5, 1, 44):
+            eng.run(n)
+        assert eng.info()["steps_done"] == 64
+        assert np.array_equal(eng.cells().view(np.uint32), ref.view(np.uint32))
+        np.testing.assert_allclose(eng.av_vels(64), ref_av, rtol=AV_RTOL)
+
+
 def test_two_steps_per_pass_random_lattice(lbm, oracle, monkeypatch):
     """Random populations / obstacles, both periodic wraps live, lid row next to a slab edge."""
     monkeypatch.setenv("LBM_FUSE2", "1")
