@@ -298,6 +298,33 @@ def test_diagnostics_match_oracle(lbm, oracle, datasets):
         assert eng.total_density() == pytest.approx(mass0, rel=1e-5)
 
 
+def test_api_misuse_returns_errors(lbm, datasets):
+    """Error behaviour of the C ABI in return-code mode (the Python host's mode): every misuse is
+    reported with a message, nothing crashes, and the context stays usable."""
+    import ctypes
+    p, ob = datasets("128x128")
+    small = lbm.Params(p.nx, p.ny, 10, p.reynolds_dim, p.density, p.accel, p.omega)
+    with lbm.Engine(small, ob) as eng:
+        eng.run(4)
+        with pytest.raises(lbm.LbmError, match="steps requested"):
+            eng.av_vels(5)                      # only 4 recorded
+        with pytest.raises(lbm.LbmError, match="negative"):
+            eng.run(-1)
+        eng.run(0)                              # no-op
+        lib = eng.lib
+        assert lib.lbm_read_av_vels(eng.handle, None, 1) != 0 and b"NULL" in lib.lbm_last_error()
+        assert lib.lbm_read_cells(eng.handle, None) != 0
+        assert lib.lbm_run(None, 1) != 0 and b"null context" in lib.lbm_last_error()
+        assert lib.lbm_get_info(eng.handle, None) != 0
+        eng.run(6)                              # still works, fills the record exactly
+        assert eng.info()["steps_done"] == 10 and np.isfinite(eng.av_vels(10)).all()
+    bad_math = 7
+    with pytest.raises(lbm.LbmError, match="math mode"):
+        h = lbm.load_library().lbm_create(ctypes.byref(small._c()), ob.ctypes.data, None, 1, bad_math)
+        if not h:
+            raise lbm.LbmError(lbm.load_library().lbm_last_error().decode())
+
+
 def test_run_beyond_record_fails(lbm, datasets):
     p, ob = datasets("128x128")
     small = lbm.Params(p.nx, p.ny, 5, p.reynolds_dim, p.density, p.accel, p.omega)
