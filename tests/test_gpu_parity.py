@@ -298,6 +298,23 @@ def test_diagnostics_match_oracle(lbm, oracle, datasets):
         assert eng.total_density() == pytest.approx(mass0, rel=1e-5)
 
 
+def test_run_to_run_determinism(lbm, datasets, monkeypatch):
+    """No atomics anywhere: per-workgroup partials reduced in a fixed order, so two runs of the same
+    configuration give bit-identical av_vels (and lattices) -- with one slab, several slabs, and
+    the two-step kernel."""
+    p, ob = datasets("256x256")
+    for fuse, slabs in (("0", 1), ("1", 1), ("1", 3)):
+        monkeypatch.setenv("LBM_FUSE2", fuse)
+        monkeypatch.setenv("LBM_HALO", "memcpy")
+        outs = []
+        for _ in range(2):
+            with lbm.Engine(p, ob, None, n_gpus=slabs) as eng:
+                eng.run(301)
+                outs.append((eng.av_vels(301).copy(), eng.cells().copy()))
+        assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32)), (fuse, slabs)
+        assert np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32)), (fuse, slabs)
+
+
 def test_api_misuse_returns_errors(lbm, datasets):
     """Error behaviour of the C ABI in return-code mode (the Python host's mode): every misuse is
     reported with a message, nothing crashes, and the context stays usable."""
