@@ -10,10 +10,15 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -91,6 +96,77 @@ struct Slab {
 constexpr int kSumBlocks = 1024;
 constexpr int kHaloRows = 2;  // halo rows kept below and above every slab (two-step kernel needs 2)
 
+// One host thread per slab for the issue loop of a one-process multi-GPU run: a pass enqueues
+// ~10 runtime calls per slab, which a single thread issues at 25-30 us per slab -- more than an
+// 8-GPU pass of 8192^2 takes on the devices.  The team runs the per-slab bodies of each phase
+// concurrently (fork-join); phases stay ordered, so event records always precede the waits of the
+// next phase.  Workers spin (yield) while a run is in flight and sleep on a condition variable
+// between runs.  Single-slab contexts and the one-process-per-GPU form have no team.
+struct SlabTeam {
+  std::vector<std::thread> threads;
+  std::function<int(int)> job;
+  std::atomic<int> generation{0};
+  std::atomic<int> pending{0};
+  std::atomic<int> failed{0};
+  std::atomic<bool> stop{false};
+  std::atomic<bool> hot{false};
+  std::mutex m;
+  std::condition_variable cv;
+  char error[kMaxSlabs][1024];
+
+  void worker(int s) {
+    int seen = 0;
+    for (;;) {
+      while (generation.load(std::memory_order_acquire) == seen && !stop.load(std::memory_order_acquire)) {
+        if (hot.load(std::memory_order_acquire)) {
+          std::this_thread::yield();
+        } else {
+          std::unique_lock<std::mutex> lk(m);
+          cv.wait_for(lk, std::chrono::milliseconds(2));
+        }
+      }
+      if (stop.load(std::memory_order_acquire)) return;
+      seen = generation.load(std::memory_order_acquire);
+      const int rc = job(s);
+      if (rc != LBM_SUCCESS) {
+        strncpy(error[s], g_last_error, sizeof(error[s]) - 1);
+        failed.store(1, std::memory_order_release);
+      }
+      pending.fetch_sub(1, std::memory_order_release);
+    }
+  }
+  void start(int n) {
+    for (int s = 0; s < n; s++) {
+      error[s][0] = 0;
+      threads.emplace_back([this, s] { worker(s); });
+    }
+  }
+  int run(int n, const std::function<int(int)>& f) {
+    job = f;
+    failed.store(0, std::memory_order_relaxed);
+    pending.store(n, std::memory_order_release);
+    generation.fetch_add(1, std::memory_order_release);
+    if (!hot.load(std::memory_order_acquire)) cv.notify_all();
+    while (pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+    if (failed.load(std::memory_order_acquire)) {
+      for (int s = 0; s < n; s++)
+        if (error[s][0]) {
+          strncpy(g_last_error, error[s], sizeof(g_last_error) - 1);
+          error[s][0] = 0;
+          break;
+        }
+      return LBM_FAILURE;
+    }
+    return LBM_SUCCESS;
+  }
+  void shutdown() {
+    stop.store(true, std::memory_order_release);
+    cv.notify_all();
+    for (auto& t : threads) t.join();
+    threads.clear();
+  }
+};
+
 }  // namespace
 
 struct lbm_ctx {
@@ -118,9 +194,18 @@ struct lbm_ctx {
   int fuse2 = 0;  // two timesteps per pass (step2_stream) when a single periodic slab allows it
   int band_rows = 8, n_strips = 0;  // step2_stream geometry: band height, waves across x
   int lane_cells = 4;               // cells per lane in step2_stream (4 or 2; LBM_LANE_CELLS)
+  SlabTeam* team = nullptr;         // one issuing thread per slab (one-process multi-GPU), or null
 };
 
 namespace {
+
+// run body(s) for every slab: concurrently on the slab team when there is one, else in order
+int for_slabs(lbm_ctx* c, const std::function<int(int)>& body) {
+  if (c->team) return c->team->run(c->n_slabs, body);
+  for (int s = 0; s < c->n_slabs; s++)
+    if (body(s) != LBM_SUCCESS) return LBM_FAILURE;
+  return LBM_SUCCESS;
+}
 
 // ---- launch helpers --------------------------------------------------------------------------
 int launch_step(lbm_ctx* c, int s, hipStream_t stream, int row_first, int row_stride, int n_rows,
@@ -230,25 +315,36 @@ int blocks_for_rows(const lbm_ctx* c, int n_rows) {
 int exchange_halos(lbm_ctx* c, int depth) {
   const long n = (long)depth * c->row_pitch;
   if (c->halo == HALO_RCCL) {
-    NCCL_TRY(LBM_FAILURE, ncclGroupStart());
-    for (int s = 0; s < c->n_slabs; s++) {
+    // one thread driving several communicators must group them; with one thread per slab each
+    // thread groups its own four operations
+    if (!c->team) NCCL_TRY(LBM_FAILURE, ncclGroupStart());
+    const int rc = for_slabs(c, [&](int s) -> int {
       Slab& sl = c->slab[s];
       float* lat = sl.lat[c->cur];
       int me, parts;
       if (c->ranked) { me = c->rank; parts = c->world; } else { me = s; parts = c->n_slabs; }
       const int north = (me + 1) % parts, south = (me - 1 + parts) % parts;
+      if (c->team) {
+        HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+        NCCL_TRY(LBM_FAILURE, ncclGroupStart());
+      }
       // order matters when north == south (2 parts): first send pairs with the peer's first recv
       NCCL_TRY(LBM_FAILURE, ncclSend(lat + (long)(sl.rows - depth) * c->row_pitch, n, ncclFloat, north, sl.nccl, sl.comm));
       NCCL_TRY(LBM_FAILURE, ncclSend(lat, n, ncclFloat, south, sl.nccl, sl.comm));
       NCCL_TRY(LBM_FAILURE, ncclRecv(lat - n, n, ncclFloat, south, sl.nccl, sl.comm));
       NCCL_TRY(LBM_FAILURE, ncclRecv(lat + (long)sl.rows * c->row_pitch, n, ncclFloat, north, sl.nccl, sl.comm));
-    }
-    NCCL_TRY(LBM_FAILURE, ncclGroupEnd());
-  } else if (c->halo == HALO_MEMCPY) {
+      if (c->team) NCCL_TRY(LBM_FAILURE, ncclGroupEnd());
+      return LBM_SUCCESS;
+    });
+    if (!c->team) NCCL_TRY(LBM_FAILURE, ncclGroupEnd());
+    return rc;
+  }
+  if (c->halo == HALO_MEMCPY) {
     // push model inside one process: slab s copies its boundary rows into its neighbours' halo rows
     // once the neighbours' boundary kernels have finished with the previous contents
-    // (ev_boundary); the neighbours' next boundary kernels wait for ev_halo of the pushing slabs.
-    for (int s = 0; s < c->n_slabs; s++) {
+    // (ev_boundary, recorded in the previous phase); the neighbours' next boundary kernels wait
+    // for ev_halo of the pushing slabs.
+    return for_slabs(c, [&](int s) -> int {
       Slab& sl = c->slab[s];
       const int north = (s + 1) % c->n_slabs, south = (s - 1 + c->n_slabs) % c->n_slabs;
       float* lat = sl.lat[c->cur];
@@ -262,7 +358,8 @@ int exchange_halos(lbm_ctx* c, int depth) {
       HIP_TRY(LBM_FAILURE, hipMemcpyAsync(ss.lat[c->cur] + (long)ss.rows * c->row_pitch, lat, n * sizeof(float),
                                           hipMemcpyDefault, sl.comm));
       HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_halo, sl.comm));
-    }
+      return LBM_SUCCESS;
+    });
   }
   return LBM_SUCCESS;
 }
@@ -270,7 +367,7 @@ int exchange_halos(lbm_ctx* c, int depth) {
 // reduce the buffered per-workgroup partials of the last slot_fill steps into tot_u[step_base...]
 int flush_partials(lbm_ctx* c, int step_base) {
   if (c->slot_fill == 0) return LBM_SUCCESS;
-  for (int s = 0; s < c->n_slabs; s++) {
+  return for_slabs(c, [&](int s) -> int {
     Slab& sl = c->slab[s];
     HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
     // the boundary rows' partials are written on the comm stream
@@ -283,20 +380,20 @@ int flush_partials(lbm_ctx* c, int step_base) {
       HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_flush, sl.compute));
       HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sl.ev_flush, 0));
     }
-  }
-  return LBM_SUCCESS;
+    return LBM_SUCCESS;
+  });
 }
 
 // The timestep loop.  Single slab: one fused launch per pass (one or two timesteps).  Several slabs / ranks
 // (the Waitall pattern of MPI_Waitall/d2q9-bgk.c:225-253, restructured for two HIP streams):
 //
-//   compute stream:  I(0) ─────────────► I(1) ─────────────► I(2) ...     interior rows 1..rows-2
-//                      ▲ waits B(t-1)      ▲
-//   comm stream:     X(0) → B(0) → X(1) → B(1) → X(2) → B(2) ...          halo exchange, boundary rows
-//                            ▲ waits I(t-1)
+//   compute stream:  I(0) ─────────────► I(1) ─────────────► I(2) ...     rows that touch no halo row
+//                      ▲ waits B(m-1)      ▲
+//   comm stream:     X(0) → B(0) → X(1) → B(1) → X(2) → B(2) ...          halo exchange, halo-touching rows
+//                            ▲ waits I(m-1)
 //
-// I(t) and B(t) both read lattice t and write disjoint rows of lattice t+1; B(t) additionally
-// needs the halos X(t) (its own stream, in order) and writes the boundary rows X(t+1) sends.  The
+// I(m) and B(m) both read lattice m and write disjoint rows of lattice m+1; B(m) additionally
+// needs the halos X(m) (its own stream, in order) and writes the boundary rows X(m+1) sends.  The
 // chain of interior kernels is the critical path; exchange and boundary rows hide beside it.
 //
 // Two-step passes across slabs: an output row y reads source rows y-2 .. y+2, so only rows 0,1 and
@@ -314,35 +411,38 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
   const float a1 = c->p.density * c->p.accel / 9.f;
   const float a2 = c->p.density * c->p.accel / 36.f;
   const bool halo = (c->halo != HALO_SELF);
+  // the slab threads spin between phases while the run is in flight
+  struct HotGuard {
+    SlabTeam* t;
+    explicit HotGuard(SlabTeam* team) : t(team) { if (t) { t->hot.store(true); t->cv.notify_all(); } }
+    ~HotGuard() { if (t) t->hot.store(false); }
+  } hot_guard(c->team);
 
   // accelerate_flow() of the first step (later steps: epilogue of the step kernel)
-  for (int s = 0; s < c->n_slabs; s++) {
-    Slab& sl = c->slab[s];
-    HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
-    if (sl.accel_row >= 0 && sl.accel_row < sl.rows) {
-      hipLaunchKernelGGL(lbm::accelerate_row, dim3(ceil_div(c->p.nx, 256)), dim3(256), 0, sl.compute,
-                         sl.lat[c->cur], sl.mask, c->plane_stride, c->row_pitch, c->pitch, c->p.nx,
-                         sl.accel_row, a1, a2);
-      HIP_TRY(LBM_FAILURE, hipGetLastError());
-    }
-    if (halo) {
-      // "I(-1)": the lattice is ready; also orders the comm stream after everything a previous
-      // lbm_run left on the compute stream
-      HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_interior[1], sl.compute));
-      HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sl.ev_interior[1], 0));
-      // boundary event in a defined state for the first memcpy exchange
-      HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_boundary, sl.comm));
-    }
-  }
+  if (for_slabs(c, [&](int s) -> int {
+        Slab& sl = c->slab[s];
+        HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+        if (sl.accel_row >= 0 && sl.accel_row < sl.rows) {
+          hipLaunchKernelGGL(lbm::accelerate_row, dim3(ceil_div(c->p.nx, 256)), dim3(256), 0, sl.compute,
+                             sl.lat[c->cur], sl.mask, c->plane_stride, c->row_pitch, c->pitch, c->p.nx,
+                             sl.accel_row, a1, a2);
+          HIP_TRY(LBM_FAILURE, hipGetLastError());
+        }
+        if (halo) {
+          // "I(-1)": the lattice is ready; also orders the comm stream after everything a previous
+          // lbm_run left on the compute stream
+          HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_interior[1], sl.compute));
+          HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sl.ev_interior[1], 0));
+          // boundary event in a defined state for the first memcpy exchange
+          HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_boundary, sl.comm));
+        }
+        if (kernel_ms) HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_t0, sl.compute));
+        return LBM_SUCCESS;
+      }) != LBM_SUCCESS)
+    return LBM_FAILURE;
   // halo depth: the two-step kernel reads two rows beyond the slab
   const int depth = c->fuse2 ? 2 : 1;
   if (halo && exchange_halos(c, depth) != LBM_SUCCESS) return LBM_FAILURE;
-
-  if (kernel_ms)
-    for (int s = 0; s < c->n_slabs; s++) {
-      HIP_TRY(LBM_FAILURE, hipSetDevice(c->slab[s].device));
-      HIP_TRY(LBM_FAILURE, hipEventRecord(c->slab[s].ev_t0, c->slab[s].compute));
-    }
 
   // macro steps: two timesteps per pass where enabled and at least two remain, else one
   int flushed_upto = c->steps_done;
@@ -351,46 +451,47 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
     const bool two = c->fuse2 && (t + 1 < n_steps);
     const int adv = two ? 2 : 1;
     const bool last = (t + adv == n_steps);
-    for (int s = 0; s < c->n_slabs; s++) {
-      Slab& sl = c->slab[s];
-      HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
-      if (halo && m > 0) HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, sl.ev_boundary, 0));  // B(m-1)
-      if (two) {
-        // whole slab when periodic; otherwise the rows that touch no halo row
-        const int r0 = halo ? 2 : 0, r1 = halo ? sl.rows - 2 : sl.rows;
-        if (launch_step2(c, s, sl.compute, r0, r1, c->band_rows, c->band_rows, ceil_div(r1 - r0, c->band_rows), 0,
-                         !last) != LBM_SUCCESS)
-          return LBM_FAILURE;
-      } else {
-        if (!halo) {
-          if (launch_step(c, s, sl.compute, 0, 1, sl.rows, 0, !last) != LBM_SUCCESS) return LBM_FAILURE;
-        } else {
-          if (launch_step(c, s, sl.compute, 1, 1, sl.rows - 2, 0, !last) != LBM_SUCCESS) return LBM_FAILURE;
-        }
-      }
-      if (halo) HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_interior[m & 1], sl.compute));
-    }
-    if (halo) {
-      // boundary rows / bands on the comm streams, behind the exchange X(m)
-      for (int s = 0; s < c->n_slabs; s++) {
-        Slab& sl = c->slab[s];
-        HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
-        HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sl.ev_interior[(m + 1) & 1], 0));  // I(m-1)
-        if (c->halo == HALO_MEMCPY) {
-          const int north = (s + 1) % c->n_slabs, south = (s - 1 + c->n_slabs) % c->n_slabs;
-          HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, c->slab[north].ev_halo, 0));
-          HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, c->slab[south].ev_halo, 0));
-        }
-        if (two) {
-          // rows 0,1 and rows-2,rows-1 as two 2-row bands in one launch
-          const int off = c->n_strips * ceil_div(sl.rows - 4, c->band_rows);
-          if (launch_step2(c, s, sl.comm, 0, sl.rows, 2, sl.rows - 2, 2, off, !last) != LBM_SUCCESS) return LBM_FAILURE;
-        } else {
-          if (launch_step(c, s, sl.comm, 0, sl.rows - 1, 2, sl.blocks_main, !last) != LBM_SUCCESS) return LBM_FAILURE;
-        }
-        HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_boundary, sl.comm));
-      }
-    }
+    // phase 1: rows that touch no halo row (or the whole slab) on the compute streams
+    if (for_slabs(c, [&](int s) -> int {
+          Slab& sl = c->slab[s];
+          HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+          if (halo && m > 0) HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, sl.ev_boundary, 0));  // B(m-1)
+          if (two) {
+            const int r0 = halo ? 2 : 0, r1 = halo ? sl.rows - 2 : sl.rows;
+            if (launch_step2(c, s, sl.compute, r0, r1, c->band_rows, c->band_rows, ceil_div(r1 - r0, c->band_rows), 0,
+                             !last) != LBM_SUCCESS)
+              return LBM_FAILURE;
+          } else if (!halo) {
+            if (launch_step(c, s, sl.compute, 0, 1, sl.rows, 0, !last) != LBM_SUCCESS) return LBM_FAILURE;
+          } else {
+            if (launch_step(c, s, sl.compute, 1, 1, sl.rows - 2, 0, !last) != LBM_SUCCESS) return LBM_FAILURE;
+          }
+          if (halo) HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_interior[m & 1], sl.compute));
+          return LBM_SUCCESS;
+        }) != LBM_SUCCESS)
+      return LBM_FAILURE;
+    // phase 2: halo-touching rows / bands on the comm streams, behind the exchange X(m)
+    if (halo &&
+        for_slabs(c, [&](int s) -> int {
+          Slab& sl = c->slab[s];
+          HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+          HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sl.ev_interior[(m + 1) & 1], 0));  // I(m-1)
+          if (c->halo == HALO_MEMCPY) {
+            const int north = (s + 1) % c->n_slabs, south = (s - 1 + c->n_slabs) % c->n_slabs;
+            HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, c->slab[north].ev_halo, 0));
+            HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, c->slab[south].ev_halo, 0));
+          }
+          if (two) {
+            // rows 0,1 and rows-2,rows-1 as two 2-row bands in one launch
+            const int off = c->n_strips * ceil_div(sl.rows - 4, c->band_rows);
+            if (launch_step2(c, s, sl.comm, 0, sl.rows, 2, sl.rows - 2, 2, off, !last) != LBM_SUCCESS) return LBM_FAILURE;
+          } else {
+            if (launch_step(c, s, sl.comm, 0, sl.rows - 1, 2, sl.blocks_main, !last) != LBM_SUCCESS) return LBM_FAILURE;
+          }
+          HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_boundary, sl.comm));
+          return LBM_SUCCESS;
+        }) != LBM_SUCCESS)
+      return LBM_FAILURE;
     // bookkeeping of the partial slots written by this macro step
     for (int s = 0; s < c->n_slabs; s++) {
       Slab& sl = c->slab[s];
@@ -402,6 +503,7 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
     c->cur ^= 1;
     c->slot_fill += adv;
     t += adv;
+    // phase 3: the next exchange
     if (halo && !last && exchange_halos(c, depth) != LBM_SUCCESS) return LBM_FAILURE;
     if (c->slot_fill >= kPartSlots - 1 || last) {
       if (flush_partials(c, flushed_upto) != LBM_SUCCESS) return LBM_FAILURE;
@@ -699,6 +801,14 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
     }
     for (int s = 0; s < n_slabs; s++) c->slab[s].nccl = comms[s];
   }
+  // one issuing thread per slab when one process drives several slabs: opt-in (LBM_THREADS=1).
+  // With several slabs on ONE device it is slower (the runtime serialises calls to a device:
+  // 65 vs 53 us per step for 2 slabs); whether it pays with one device per slab could not be
+  // measured on the 1-GPU box.
+  if (n_slabs > 1 && env_int("LBM_THREADS", 0)) {
+    c->team = new SlabTeam();
+    c->team->start(n_slabs);
+  }
   return c;
 }
 
@@ -757,6 +867,11 @@ lbm_ctx* lbm_create_rank(const lbm_params* params, const int* obstacles, const f
 
 void lbm_destroy(lbm_ctx* c) {
   if (!c) return;
+  if (c->team) {
+    c->team->shutdown();
+    delete c->team;
+    c->team = nullptr;
+  }
   for (int s = 0; s < c->n_slabs; s++) {
     if (c->slab[s].compute) {
       (void)hipSetDevice(c->slab[s].device);

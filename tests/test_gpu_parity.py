@@ -298,6 +298,21 @@ def test_diagnostics_match_oracle(lbm, oracle, datasets):
         assert eng.total_density() == pytest.approx(mass0, rel=1e-5)
 
 
+def test_slab_thread_team(lbm, oracle, datasets, monkeypatch):
+    """LBM_THREADS=1: one issuing host thread per slab (fork-join per phase).  Same results."""
+    monkeypatch.setenv("LBM_THREADS", "1")
+    monkeypatch.setenv("LBM_HALO", "memcpy")
+    monkeypatch.setenv("LBM_FUSE2", "1")
+    p, ob = datasets("128x256")
+    cells = oracle.init_cells(p)
+    ref_cells, ref_av, got_cells, got_av, _ = run_both(lbm, oracle, p, ob, cells, 101, n_gpus=4)
+    assert np.array_equal(ref_cells.view(np.uint32), got_cells.view(np.uint32))
+    np.testing.assert_allclose(got_av, ref_av, rtol=AV_RTOL)
+    monkeypatch.setenv("LBM_FUSE2", "0")
+    ref_cells, ref_av, got_cells, got_av, _ = run_both(lbm, oracle, p, ob, cells, 50, n_gpus=3)
+    assert np.array_equal(ref_cells.view(np.uint32), got_cells.view(np.uint32))
+
+
 def test_run_to_run_determinism(lbm, datasets, monkeypatch):
     """No atomics anywhere: per-workgroup partials reduced in a fixed order, so two runs of the same
     configuration give bit-identical av_vels (and lattices) -- with one slab, several slabs, and
