@@ -740,13 +740,15 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
   c->lane_cells = env_int("LBM_LANE_CELLS", min_cells >= 6L * 1024 * 1024 ? 4 : 2) == 2 ? 2 : 4;
   c->n_strips = ceil_div(params->nx / c->lane_cells > 0 ? params->nx / c->lane_cells : 1, lbm::kStripQuads);
   // Band height.  A wave sweeps band_rows + 2 rows.  4-cell form: 256 CUs x 12 waves are resident
-  // at once; big slabs run many rounds of waves and like short bands (8: measured best at 8192^2
-  // and 4096^2), a slab that fits in a few rounds is quantised by them -- pick the height that
+  // at once; big slabs run many rounds of waves and like short bands (5-6 rows),
+  // a slab that fits in a few rounds is quantised by them -- pick the height that
   // fills k rounds exactly (8192x1024: 12 rows = 0.95 rounds 76.7 us, 11 rows = 1.04 rounds
   // 87.7 us).  The 2-cell form (mid-size grids) keeps 256 x 20 waves resident; same rule
   // (1536^2: 4 rows = 0.98 rounds 24.0 us, 8 rows 25.3 us).
   {
-    int pick = 8;
+    // many rounds of waves: measured optimum 6-7 rows up to 8192 cells per row (8192^2: 480 us vs
+    // 515 at 8), 5 at 12288 (747 vs 811), 4 at 16384 and wider (16384^2: 1993 vs 2282 us at 8)
+    int pick = (params->nx <= 8192) ? 6 : (params->nx <= 12288 ? 5 : 4);
     const long resident = 256L * 4 * (c->lane_cells == 4 ? 3 : 5);  // waves resident at once
     const long slab_rows = (n_slabs > 1 || world > 1) ? (c->row_count / n_slabs) - 4 : c->row_count;
     const long rows_eff = slab_rows > 1 ? slab_rows : 1;
