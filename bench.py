@@ -237,11 +237,12 @@ def main():
                          "kernel": kernel_name, "steps_per_launch": steps_per_launch,
                          "launch_ms": launch_ms, "kernel_ms_per_step": kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes,
-                         "hbm_GBps_actual": (traffic / (launch_ms * 1e-3) / 1e9) if traffic else None,
+                         "traffic_GBps": (traffic / (launch_ms * 1e-3) / 1e9) if traffic else None,
                          "note": ("achieved = algorithmic bytes (72 B per lattice update) / launch time; "
                                   "the two-step kernel reads and writes the lattice once per TWO updates, "
                                   "so achieved may exceed the HBM peak while the bytes actually moved "
-                                  "(traffic, from rocprofv3 PMC) stay below it") if steps_per_launch == 2
+                                  "(traffic: rocprofv3 PMC at the L2-fabric boundary, Infinity-Cache hits "
+                                  "included) stay below the algorithmic count") if steps_per_launch == 2
                          else "achieved = algorithmic bytes (72 B per lattice update) / launch time"},
             "results_finite": finite,
         }
