@@ -554,7 +554,8 @@ void free_slab(Slab& sl) {
 }
 
 bool validate_params(const lbm_params* p) {
-  return p && p->nx >= 1 && p->ny >= 2 && p->max_iters >= 0;
+  // the cell count must fit the reference's int counters (tot_cells, SerialCode/d2q9-bgk.c:411)
+  return p && p->nx >= 1 && p->ny >= 2 && p->max_iters >= 0 && (long)p->nx * (long)p->ny <= 2147483647L;
 }
 
 // Build one slab: allocate, upload mask rows, fill the lattice.

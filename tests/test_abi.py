@@ -73,6 +73,13 @@ def test_create_fails_loudly_without_device_or_with_bad_args(lbm, datasets):
         lbm.Engine(bad, ob)
     with pytest.raises(lbm.LbmError):
         lbm.Engine(p, ob, n_gpus=99)
+    # more cells than an int can count (the reference's tot_cells is an int): rejected by the C side
+    import ctypes
+    huge = lbm.Params(65536, 65536, 1, 10, 0.1, 0.005, 1.85)
+    lib = lbm.load_library()
+    dummy = np.zeros(4, dtype=np.int32)
+    assert not lib.lbm_create(ctypes.byref(huge._c()), dummy.ctypes.data, None, 1, 0)
+    assert b"invalid parameters" in lib.lbm_last_error()
 
 
 def test_die_mode_matches_reference_message_shape(lbm):
