@@ -41,6 +41,13 @@ extern "C" {
                             the lattice is bit-identical to SerialCode's */
 #define LBM_MATH_FAST  1 /* reciprocal multiplies + FMA; validated through the check.py rule */
 
+/* How a pass across several slabs / ranks treats its halo rows */
+#define LBM_HALO_SYNC  0 /* halo rows of the same timestep: the MPI_Waitall pattern
+                            (MPI_Waitall/d2q9-bgk.c:225-253); results equal the single-domain run */
+#define LBM_HALO_STALE 1 /* halo rows one pass old: reproducible analogue of the reference's
+                            MPI_Testall "stale halo" variant (MPI_Testall_OptimizedVersion/
+                            d2q9-bgk.c:256-301); no pass ever waits for an exchange of its own */
+
 /* Run constants: field-for-field the reference's t_param (SerialCode/d2q9-bgk.c:66-75). */
 typedef struct {
   int   nx;           /* cells in x */
@@ -66,6 +73,7 @@ typedef struct {
   int    world_size;     /* number of processes sharing the grid (1 otherwise) */
   int    steps_per_launch; /* timesteps one launch of the main kernel advances: 2 when the
                               two-steps-per-pass kernel is active (large grids), else 1 */
+  int    halo_mode;      /* LBM_HALO_SYNC or LBM_HALO_STALE (meaningful with several slabs / ranks) */
 } lbm_info;
 
 /* ---- error handling -------------------------------------------------------------------- */
@@ -119,6 +127,16 @@ lbm_ctx* lbm_create_rank(const lbm_params* params, const int* obstacles, const f
 
 void     lbm_destroy(lbm_ctx* ctx);
 int      lbm_get_info(const lbm_ctx* ctx, lbm_info* out);
+
+/*
+ * Halo treatment for the following lbm_run calls (default LBM_HALO_SYNC, or LBM_HALO_STALE when the
+ * environment holds LBM_HALO_MODE=stale).  Replaces the choice between the reference's
+ * MPI_Waitall and MPI_Testall_OptimizedVersion programs (main loop :256-301 of the latter).
+ * In stale mode every lbm_run call starts from freshly exchanged halos; from its second pass on, a
+ * pass reads the halo rows its neighbours produced one pass earlier.  Every rank of a multi-process
+ * run must select the same mode.  No effect on a single periodic slab.
+ */
+int      lbm_set_halo_mode(lbm_ctx* ctx, int mode);
 
 /* ---- the hot path ------------------------------------------------------------------------
  * lbm_run replaces n_steps trips of the driver loop (SerialCode/d2q9-bgk.c:166-170):

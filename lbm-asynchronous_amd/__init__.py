@@ -31,12 +31,15 @@ MATH_EXACT = 0
 MATH_FAST = 1
 _MATH = {"exact": MATH_EXACT, "fast": MATH_FAST, MATH_EXACT: MATH_EXACT, MATH_FAST: MATH_FAST}
 RCCL_ID_BYTES = 128
+HALO_SYNC = 0
+HALO_STALE = 1
+_HALO = {"sync": HALO_SYNC, "stale": HALO_STALE, HALO_SYNC: HALO_SYNC, HALO_STALE: HALO_STALE}
 
 # every symbol include/lbm_hip.h declares (tests check the .so exports them all)
 ABI_SYMBOLS = (
     "lbm_set_error_mode", "lbm_last_error", "lbm_version", "lbm_device_count",
     "lbm_partition_rows", "lbm_create", "lbm_rccl_unique_id", "lbm_create_rank", "lbm_destroy",
-    "lbm_get_info", "lbm_run", "lbm_sync", "lbm_run_timed", "lbm_read_av_vels", "lbm_read_cells",
+    "lbm_get_info", "lbm_set_halo_mode", "lbm_run", "lbm_sync", "lbm_run_timed", "lbm_read_av_vels", "lbm_read_cells",
     "lbm_read_final_state", "lbm_av_velocity", "lbm_total_density", "lbm_calc_reynolds",
 )
 
@@ -55,7 +58,8 @@ class _CInfo(ctypes.Structure):
     _fields_ = [("n_slabs", ctypes.c_int), ("row_first", ctypes.c_int), ("row_count", ctypes.c_int),
                 ("fluid_cells", ctypes.c_int), ("steps_done", ctypes.c_int),
                 ("math_mode", ctypes.c_int), ("world_rank", ctypes.c_int),
-                ("world_size", ctypes.c_int), ("steps_per_launch", ctypes.c_int)]
+                ("world_size", ctypes.c_int), ("steps_per_launch", ctypes.c_int),
+                ("halo_mode", ctypes.c_int)]
 
 
 @dataclass
@@ -109,6 +113,7 @@ def load_library() -> ctypes.CDLL:
     lib.lbm_create_rank.restype = P
     lib.lbm_destroy.argtypes = [P]; lib.lbm_destroy.restype = None
     lib.lbm_get_info.argtypes = [P, ctypes.POINTER(_CInfo)]; lib.lbm_get_info.restype = I
+    lib.lbm_set_halo_mode.argtypes = [P, I]; lib.lbm_set_halo_mode.restype = I
     lib.lbm_run.argtypes = [P, I]; lib.lbm_run.restype = I
     lib.lbm_sync.argtypes = [P]; lib.lbm_sync.restype = I
     lib.lbm_run_timed.argtypes = [P, I, PF]; lib.lbm_run_timed.restype = I
@@ -208,6 +213,13 @@ class Engine:
         ci = _CInfo()
         _check(self.lib, self.lib.lbm_get_info(self.handle, ctypes.byref(ci)))
         return {name: getattr(ci, name) for name, _ in _CInfo._fields_}
+
+    def set_halo_mode(self, mode) -> None:
+        """'sync' (halo rows of the same timestep, the MPI_Waitall pattern) or 'stale' (one pass
+        old: reproducible analogue of the reference's MPI_Testall variant)."""
+        if mode not in _HALO:
+            raise LbmError(f"unknown halo mode {mode!r}")
+        _check(self.lib, self.lib.lbm_set_halo_mode(self.handle, _HALO[mode]))
 
     # -- hot path ----------------------------------------------------------------------------
     def run(self, n_steps: int) -> None:

@@ -87,6 +87,8 @@ struct Slab {
   hipEvent_t ev_boundary = nullptr, ev_halo = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
   hipEvent_t ev_interior[2] = {nullptr, nullptr};  // interior kernel of step t -> [t & 1]
   hipEvent_t ev_flush = nullptr;                   // partials reduced: their slots may be reused
+  hipEvent_t ev_step = nullptr;                    // stale-halo mode: whole-slab pass finished
+  hipEvent_t ev_x[2] = {nullptr, nullptr};         // stale-halo mode: exchange for pass m landed -> [(m + 1) & 1]
   ncclComm_t nccl = nullptr;
   lbm::SlotCounts slot_counts;  // partials written into each buffered slot (launch geometries differ)
   int blocks_main = 0;      // interior rows (or all rows in HALO_SELF)
@@ -182,6 +184,7 @@ struct lbm_ctx {
   int fluid_cells = 0;
   int math_mode = LBM_MATH_EXACT;
   int halo = HALO_SELF;
+  int halo_mode = LBM_HALO_SYNC;  // LBM_HALO_STALE: passes consume the halos of the previous pass
   int rank = 0, world = 1;  // multi-process
   bool ranked = false;      // created by lbm_create_rank (owns an ncclCommInitRank communicator)
   int row_first = 0, row_count = 0;
@@ -304,23 +307,39 @@ int blocks_for_rows(const lbm_ctx* c, int n_rows) {
 }
 
 // One halo exchange, enqueued on the comm streams: the `depth` boundary rows at each end of every
-// slab's CURRENT lattice travel, whole (all 9 speeds, as MPI_Waitall/d2q9-bgk.c:225-230 ships
-// them), into the halo rows of its ring neighbours' current lattices -- zero copy on both sides,
+// slab's lattice `src` travel, whole (all 9 speeds, as MPI_Waitall/d2q9-bgk.c:225-230 ships
+// them), into the halo rows of its ring neighbours' lattices `dst` -- zero copy on both sides,
 // because halo rows and boundary rows are contiguous in the row-interleaved layout.
 //   my rows [rows-depth, rows)  ->  north neighbour's rows [-depth, 0)
 //   my rows [0, depth)          ->  south neighbour's rows [rows_s, rows_s + depth)
 // north neighbour of slab s = s+1 (periodic), south = s-1; across processes the ring runs over
-// ranks (MPI/d2q9-bgk.c:210-211).  Precondition (stream order): the kernels that wrote the
-// boundary rows are ordered before this on the comm stream.
-int exchange_halos(lbm_ctx* c, int depth) {
+// ranks (MPI/d2q9-bgk.c:210-211).
+// Synchronous pipeline (slot < 0): src == dst == the current lattice.  Precondition (stream order):
+// the kernels that wrote the boundary rows are ordered before this on the comm stream.
+// Stale-halo pipeline (slot 0/1): src = the lattice just produced, dst = the lattice the pass after
+// next reads.  The comm stream first waits for ev_step of this slab (boundary rows written) and, where
+// this slab writes into its neighbours' memory itself (memcpy), of the neighbours (they have finished
+// reading the halo rows about to be overwritten); ev_x[slot] marks the arrival.
+int exchange_halos(lbm_ctx* c, int depth, int src, int dst, int slot) {
   const long n = (long)depth * c->row_pitch;
+  const bool stale = (slot >= 0);
   if (c->halo == HALO_RCCL) {
+    if (stale) {
+      for (int s = 0; s < c->n_slabs; s++) {
+        Slab& sl = c->slab[s];
+        HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+        // a peer's receive is posted behind the peer's own ev_step wait, so nothing lands in halo
+        // rows a running pass still reads
+        HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sl.ev_step, 0));
+      }
+    }
     // one thread driving several communicators must group them; with one thread per slab each
     // thread groups its own four operations
     if (!c->team) NCCL_TRY(LBM_FAILURE, ncclGroupStart());
     const int rc = for_slabs(c, [&](int s) -> int {
       Slab& sl = c->slab[s];
-      float* lat = sl.lat[c->cur];
+      float* from = sl.lat[src];
+      float* to = sl.lat[dst];
       int me, parts;
       if (c->ranked) { me = c->rank; parts = c->world; } else { me = s; parts = c->n_slabs; }
       const int north = (me + 1) % parts, south = (me - 1 + parts) % parts;
@@ -329,35 +348,44 @@ int exchange_halos(lbm_ctx* c, int depth) {
         NCCL_TRY(LBM_FAILURE, ncclGroupStart());
       }
       // order matters when north == south (2 parts): first send pairs with the peer's first recv
-      NCCL_TRY(LBM_FAILURE, ncclSend(lat + (long)(sl.rows - depth) * c->row_pitch, n, ncclFloat, north, sl.nccl, sl.comm));
-      NCCL_TRY(LBM_FAILURE, ncclSend(lat, n, ncclFloat, south, sl.nccl, sl.comm));
-      NCCL_TRY(LBM_FAILURE, ncclRecv(lat - n, n, ncclFloat, south, sl.nccl, sl.comm));
-      NCCL_TRY(LBM_FAILURE, ncclRecv(lat + (long)sl.rows * c->row_pitch, n, ncclFloat, north, sl.nccl, sl.comm));
+      NCCL_TRY(LBM_FAILURE, ncclSend(from + (long)(sl.rows - depth) * c->row_pitch, n, ncclFloat, north, sl.nccl, sl.comm));
+      NCCL_TRY(LBM_FAILURE, ncclSend(from, n, ncclFloat, south, sl.nccl, sl.comm));
+      NCCL_TRY(LBM_FAILURE, ncclRecv(to - n, n, ncclFloat, south, sl.nccl, sl.comm));
+      NCCL_TRY(LBM_FAILURE, ncclRecv(to + (long)sl.rows * c->row_pitch, n, ncclFloat, north, sl.nccl, sl.comm));
       if (c->team) NCCL_TRY(LBM_FAILURE, ncclGroupEnd());
       return LBM_SUCCESS;
     });
     if (!c->team) NCCL_TRY(LBM_FAILURE, ncclGroupEnd());
-    return rc;
+    if (rc != LBM_SUCCESS) return rc;
+    if (stale) {
+      for (int s = 0; s < c->n_slabs; s++) {
+        Slab& sl = c->slab[s];
+        HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+        HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_x[slot], sl.comm));
+      }
+    }
+    return LBM_SUCCESS;
   }
   if (c->halo == HALO_MEMCPY) {
     // push model inside one process: slab s copies its boundary rows into its neighbours' halo rows
-    // once the neighbours' boundary kernels have finished with the previous contents
-    // (ev_boundary, recorded in the previous phase); the neighbours' next boundary kernels wait
-    // for ev_halo of the pushing slabs.
+    // once the neighbours have finished with the previous contents (synchronous: their boundary
+    // kernels, ev_boundary, recorded in the previous phase; stale: their whole-slab pass, ev_step);
+    // the neighbours' next halo-reading kernels wait for ev_halo / ev_x[slot] of the pushing slabs.
     return for_slabs(c, [&](int s) -> int {
       Slab& sl = c->slab[s];
       const int north = (s + 1) % c->n_slabs, south = (s - 1 + c->n_slabs) % c->n_slabs;
-      float* lat = sl.lat[c->cur];
+      float* from = sl.lat[src];
       Slab& sn = c->slab[north];
       Slab& ss = c->slab[south];
       HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
-      HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sn.ev_boundary, 0));
-      HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, ss.ev_boundary, 0));
-      HIP_TRY(LBM_FAILURE, hipMemcpyAsync(sn.lat[c->cur] - n, lat + (long)(sl.rows - depth) * c->row_pitch,
+      if (stale) HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sl.ev_step, 0));
+      HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, stale ? sn.ev_step : sn.ev_boundary, 0));
+      HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, stale ? ss.ev_step : ss.ev_boundary, 0));
+      HIP_TRY(LBM_FAILURE, hipMemcpyAsync(sn.lat[dst] - n, from + (long)(sl.rows - depth) * c->row_pitch,
                                           n * sizeof(float), hipMemcpyDefault, sl.comm));
-      HIP_TRY(LBM_FAILURE, hipMemcpyAsync(ss.lat[c->cur] + (long)ss.rows * c->row_pitch, lat, n * sizeof(float),
+      HIP_TRY(LBM_FAILURE, hipMemcpyAsync(ss.lat[dst] + (long)ss.rows * c->row_pitch, from, n * sizeof(float),
                                           hipMemcpyDefault, sl.comm));
-      HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_halo, sl.comm));
+      HIP_TRY(LBM_FAILURE, hipEventRecord(stale ? sl.ev_x[slot] : sl.ev_halo, sl.comm));
       return LBM_SUCCESS;
     });
   }
@@ -371,11 +399,12 @@ int flush_partials(lbm_ctx* c, int step_base) {
     Slab& sl = c->slab[s];
     HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
     // the boundary rows' partials are written on the comm stream
-    if (c->halo != HALO_SELF) HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, sl.ev_boundary, 0));
+    const bool split = (c->halo != HALO_SELF && c->halo_mode == LBM_HALO_SYNC);
+    if (split) HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, sl.ev_boundary, 0));
     hipLaunchKernelGGL(lbm::reduce_partials, dim3(c->slot_fill), dim3(lbm::kBlock), 0, sl.compute,
                        sl.partials, sl.slot_counts, c->part_stride, sl.tot_u, step_base);
     HIP_TRY(LBM_FAILURE, hipGetLastError());
-    if (c->halo != HALO_SELF) {
+    if (split) {
       // the next boundary kernels (comm stream) reuse the partial slots just read
       HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_flush, sl.compute));
       HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sl.ev_flush, 0));
@@ -399,6 +428,8 @@ int flush_partials(lbm_ctx* c, int step_base) {
 // Two-step passes across slabs: an output row y reads source rows y-2 .. y+2, so only rows 0,1 and
 // rows-2, rows-1 touch halo rows.  They form two 2-row bands (short sweeps: low latency on the comm
 // stream); rows [2, rows-2) are the interior region, cut into bands of band_rows.
+int run_steps_stale(lbm_ctx* c, int n_steps, float* kernel_ms);
+
 int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
   if (!c) LBM_FAIL(LBM_FAILURE, "lbm_run: null context");
   if (n_steps < 0) LBM_FAIL(LBM_FAILURE, "lbm_run: negative step count");
@@ -407,6 +438,7 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
   if (c->steps_done + n_steps > c->capacity)
     LBM_FAIL(LBM_FAILURE, "lbm_run: %d steps requested but the av_vels record holds %d (maxIters)",
              c->steps_done + n_steps, c->capacity);
+  if (c->halo != HALO_SELF && c->halo_mode == LBM_HALO_STALE) return run_steps_stale(c, n_steps, kernel_ms);
 
   const float a1 = c->p.density * c->p.accel / 9.f;
   const float a2 = c->p.density * c->p.accel / 36.f;
@@ -442,7 +474,7 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
     return LBM_FAILURE;
   // halo depth: the two-step kernel reads two rows beyond the slab
   const int depth = c->fuse2 ? 2 : 1;
-  if (halo && exchange_halos(c, depth) != LBM_SUCCESS) return LBM_FAILURE;
+  if (halo && exchange_halos(c, depth, c->cur, c->cur, -1) != LBM_SUCCESS) return LBM_FAILURE;
 
   // macro steps: two timesteps per pass where enabled and at least two remain, else one
   int flushed_upto = c->steps_done;
@@ -504,7 +536,7 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
     c->slot_fill += adv;
     t += adv;
     // phase 3: the next exchange
-    if (halo && !last && exchange_halos(c, depth) != LBM_SUCCESS) return LBM_FAILURE;
+    if (halo && !last && exchange_halos(c, depth, c->cur, c->cur, -1) != LBM_SUCCESS) return LBM_FAILURE;
     if (c->slot_fill >= kPartSlots - 1 || last) {
       if (flush_partials(c, flushed_upto) != LBM_SUCCESS) return LBM_FAILURE;
       flushed_upto += c->slot_fill;
@@ -514,6 +546,131 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
   c->steps_done += n_steps;
   // (the last flush made every compute stream wait for its final boundary kernel)
 
+  if (kernel_ms) {
+    float worst = 0.f;
+    for (int s = 0; s < c->n_slabs; s++) {
+      Slab& sl = c->slab[s];
+      HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+      HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_t1, sl.compute));
+    }
+    for (int s = 0; s < c->n_slabs; s++) {
+      Slab& sl = c->slab[s];
+      HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+      HIP_TRY(LBM_FAILURE, hipEventSynchronize(sl.ev_t1));
+      float ms = 0.f;
+      HIP_TRY(LBM_FAILURE, hipEventElapsedTime(&ms, sl.ev_t0, sl.ev_t1));
+      if (ms > worst) worst = ms;
+    }
+    *kernel_ms = worst / (float)n_steps;
+  }
+  return LBM_SUCCESS;
+}
+
+// Stale-halo ("asynchronous") timestep loop: the GPU analogue of the reference's research variant,
+// MPI_Testall_OptimizedVersion/d2q9-bgk.c:256-301, which replaces MPI_Waitall by MPI_Testall and relaxes
+// the boundary rows with whatever halo contents are there.  Here the staleness is pinned to exactly
+// one pass, which keeps the run reproducible: pass m reads its own rows of lattice m but the halo
+// rows its neighbours sent from lattice m-1 (pass 0 of every lbm_run call starts from fresh halos).
+// Nothing on the compute stream ever waits for an exchange issued in the same pass:
+//
+//   compute stream:  S(0) ──────► S(1) ──────► S(2) ──────► S(3) ...    whole slab, one launch per pass
+//                      │  ▲ X'(0)   │  ▲ X'(1)   │  ▲ X'(2)
+//   comm stream:       └► X'(1) ────┴► X'(2) ────┴► X'(3) ...            X'(k): boundary rows of lattice k
+//                                                                         -> halo rows S(k+1) reads
+//
+// X'(k) starts when S(k-1) has written lattice k and has a whole pass to land.  It writes the halo
+// rows of the OTHER lattice buffer (the one S(k+1) reads), which S(k-1) finished reading and S(k)
+// never touches, so there is no torn read -- unlike the reference, whose Irecv may land mid-row.
+// Stale passes always advance ONE timestep, also where the synchronous pipeline uses the two-step kernel:
+// then every population that crosses a slab boundary is simply delayed by one step -- nothing is lost or
+// duplicated, steady states are unchanged, and the transient stays within 1 % (2 slabs) .. 4 % (8 slabs
+// of 16 rows) of the synchronous run on the reference's 128x128 case.  With two steps per pass the
+// redundantly relaxed halo-adjacent rows would be computed from stale data on one side of the seam and
+// from fresh data on the other, which no longer conserves mass: measured, that variant drifts past the
+// 1 % rule with 2 slabs and diverges to NaN after 2172 steps with 8 (profiles/r01_tuning.md).
+int run_steps_stale(lbm_ctx* c, int n_steps, float* kernel_ms) {
+  const float a1 = c->p.density * c->p.accel / 9.f;
+  const float a2 = c->p.density * c->p.accel / 36.f;
+  const int depth = 1;  // one timestep per pass (see above): only the adjacent row is read
+  struct HotGuard {
+    SlabTeam* t;
+    explicit HotGuard(SlabTeam* team) : t(team) { if (t) { t->hot.store(true); t->cv.notify_all(); } }
+    ~HotGuard() { if (t) t->hot.store(false); }
+  } hot_guard(c->team);
+
+  // accelerate_flow() of the first step, then fresh halos for pass 0 (same lattice) and, from the same
+  // rows, the one-pass-old halos of pass 1 (other lattice)
+  if (for_slabs(c, [&](int s) -> int {
+        Slab& sl = c->slab[s];
+        HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+        if (sl.accel_row >= 0 && sl.accel_row < sl.rows) {
+          hipLaunchKernelGGL(lbm::accelerate_row, dim3(ceil_div(c->p.nx, 256)), dim3(256), 0, sl.compute,
+                             sl.lat[c->cur], sl.mask, c->plane_stride, c->row_pitch, c->pitch, c->p.nx,
+                             sl.accel_row, a1, a2);
+          HIP_TRY(LBM_FAILURE, hipGetLastError());
+        }
+        HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_step, sl.compute));
+        if (kernel_ms) HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_t0, sl.compute));
+        return LBM_SUCCESS;
+      }) != LBM_SUCCESS)
+    return LBM_FAILURE;
+  if (exchange_halos(c, depth, c->cur, c->cur, 1) != LBM_SUCCESS) return LBM_FAILURE;      // read by S(0)
+  if (exchange_halos(c, depth, c->cur, c->cur ^ 1, 0) != LBM_SUCCESS) return LBM_FAILURE;  // read by S(1)
+
+  int flushed_upto = c->steps_done;
+  int m = 0;
+  for (int t = 0; t < n_steps; m++) {
+    const bool two = false;
+    const int adv = 1;
+    const bool last = (t + adv == n_steps);
+    const int slot = (m + 1) & 1;  // the exchange S(m) consumes: issued during pass m-2 (or the prologue)
+    if (for_slabs(c, [&](int s) -> int {
+          Slab& sl = c->slab[s];
+          HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+          // own exchange: my halo rows have landed (RCCL) and the boundary rows of the lattice this pass
+          // overwrites have been read out (the copies X'(m-1) made from it)
+          HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, sl.ev_x[slot], 0));
+          if (c->halo == HALO_MEMCPY) {
+            // push model: my halo rows are written by the neighbours' streams
+            const int north = (s + 1) % c->n_slabs, south = (s - 1 + c->n_slabs) % c->n_slabs;
+            HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, c->slab[north].ev_x[slot], 0));
+            HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, c->slab[south].ev_x[slot], 0));
+          }
+          if (two) {
+            if (launch_step2(c, s, sl.compute, 0, sl.rows, c->band_rows, c->band_rows, ceil_div(sl.rows, c->band_rows), 0,
+                             !last) != LBM_SUCCESS)
+              return LBM_FAILURE;
+          } else {
+            if (launch_step(c, s, sl.compute, 0, 1, sl.rows, 0, !last) != LBM_SUCCESS) return LBM_FAILURE;
+          }
+          HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_step, sl.compute));
+          return LBM_SUCCESS;
+        }) != LBM_SUCCESS)
+      return LBM_FAILURE;
+    for (int s = 0; s < c->n_slabs; s++) {
+      Slab& sl = c->slab[s];
+      const int n_part = two ? c->n_strips * ceil_div(sl.rows, c->band_rows) : blocks_for_rows(c, sl.rows);
+      for (int k = 0; k < adv; k++) sl.slot_counts.n[c->slot_fill + k] = n_part;
+    }
+    c->cur ^= 1;
+    c->slot_fill += adv;
+    t += adv;
+    // X'(m+1): the rows S(m) just produced, for S(m+2)
+    if (!last && exchange_halos(c, depth, c->cur, c->cur ^ 1, slot) != LBM_SUCCESS) return LBM_FAILURE;
+    if (c->slot_fill >= kPartSlots - 1 || last) {
+      if (flush_partials(c, flushed_upto) != LBM_SUCCESS) return LBM_FAILURE;
+      flushed_upto += c->slot_fill;
+      c->slot_fill = 0;
+    }
+  }
+  c->steps_done += n_steps;
+
+  // leave the comm streams ordered before whatever the host enqueues on the compute streams next
+  for (int s = 0; s < c->n_slabs; s++) {
+    Slab& sl = c->slab[s];
+    HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+    for (int i = 0; i < 2; i++) HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, sl.ev_x[i], 0));
+  }
   if (kernel_ms) {
     float worst = 0.f;
     for (int s = 0; s < c->n_slabs; s++) {
@@ -546,6 +703,8 @@ void free_slab(Slab& sl) {
   if (sl.ev_halo) (void)hipEventDestroy(sl.ev_halo);
   for (int i = 0; i < 2; i++) if (sl.ev_interior[i]) (void)hipEventDestroy(sl.ev_interior[i]);
   if (sl.ev_flush) (void)hipEventDestroy(sl.ev_flush);
+  if (sl.ev_step) (void)hipEventDestroy(sl.ev_step);
+  for (int i = 0; i < 2; i++) if (sl.ev_x[i]) (void)hipEventDestroy(sl.ev_x[i]);
   if (sl.ev_t0) (void)hipEventDestroy(sl.ev_t0);
   if (sl.ev_t1) (void)hipEventDestroy(sl.ev_t1);
   if (sl.compute) (void)hipStreamDestroy(sl.compute);
@@ -569,6 +728,8 @@ int build_slab(lbm_ctx* c, int s, const int* obstacles, const float* cells_aos) 
   HIP_TRY(LBM_FAILURE, hipEventCreateWithFlags(&sl.ev_halo, hipEventDisableTiming));
   for (int i = 0; i < 2; i++) HIP_TRY(LBM_FAILURE, hipEventCreateWithFlags(&sl.ev_interior[i], hipEventDisableTiming));
   HIP_TRY(LBM_FAILURE, hipEventCreateWithFlags(&sl.ev_flush, hipEventDisableTiming));
+  HIP_TRY(LBM_FAILURE, hipEventCreateWithFlags(&sl.ev_step, hipEventDisableTiming));
+  for (int i = 0; i < 2; i++) HIP_TRY(LBM_FAILURE, hipEventCreateWithFlags(&sl.ev_x[i], hipEventDisableTiming));
   HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_halo, sl.comm));
   HIP_TRY(LBM_FAILURE, hipEventCreate(&sl.ev_t0));
   HIP_TRY(LBM_FAILURE, hipEventCreate(&sl.ev_t1));
@@ -662,11 +823,6 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
   c->pitch = (int)round_up(params->nx, 64);
   c->plane_stride = c->pitch + env_int("LBM_PLANE_PAD_FLOATS", 0) / 4 * 4;
   c->row_pitch = 9 * c->plane_stride;
-  // 4 cells per lane need nx % 4 == 0; tiny grids are latency-bound and run faster with one cell per
-  // lane (4x the waves, a quarter of the dependent arithmetic per lane: 128^2 3.2 vs 5.0 us per step,
-  // 256^2 3.8 vs 5.2; from 512^2 on the 4-cell kernel wins)
-  c->vec4 = (params->nx % 4 == 0) &&
-            env_int("LBM_VEC4", (long)params->nx * params->ny >= 128L * 1024 ? 1 : 0);
   c->neigh = env_int("LBM_NEIGH", 0);
   if (c->neigh < 0 || c->neigh > 2) c->neigh = 0;
   // nontemporal stores pay once the two lattices no longer fit the 256 MiB Infinity Cache
@@ -691,6 +847,19 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
               : (h && !strcmp(h, "rccl")) ? HALO_RCCL
               : (distinct ? HALO_RCCL : HALO_MEMCPY);
   } else c->halo = HALO_SELF;
+
+  {
+    const char* hm = getenv("LBM_HALO_MODE");
+    if (hm && !strcmp(hm, "stale")) c->halo_mode = LBM_HALO_STALE;
+  }
+
+  // 4 cells per lane need nx % 4 == 0; tiny single-slab grids are latency-bound and run faster with one
+  // cell per lane (4x the waves, a quarter of the dependent arithmetic per lane: 128^2 3.2 vs 5.0 us per
+  // step, 256^2 3.8 vs 5.2; from 512^2 on the 4-cell kernel wins).  Asking for the two-step kernel,
+  // which exists in the 4- and 2-cell forms only, implies vec4; so do halos (see below).
+  const bool halo_on = (c->halo != HALO_SELF);
+  c->vec4 = (params->nx % 4 == 0) &&
+            env_int("LBM_VEC4", ((long)params->nx * params->ny >= 128L * 1024 || env_int("LBM_FUSE2", 0) == 1 || halo_on) ? 1 : 0);
 
   int max_blocks = 0;
   for (int s = 0; s < n_slabs; s++) {
@@ -729,8 +898,9 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
   }
   // two-steps-per-pass geometry (single periodic slab only)
   // ---- which kernel, and its geometry (all measured on MI355X; profiles/r01_tuning.md) --------
-  //   slab < 1.5 Mi cells: one timestep per pass (step_vec4); the grid is cache resident and one
-  //                        resident wave of workgroups covers it (1024^2: 13.5 us vs 13.8+ two-step)
+  //   slab < 1.5 Mi cells: single periodic slab: one timestep per pass (step_vec4); the grid is cache
+  //                        resident and one resident wave of workgroups covers it (1024^2: 13.5 us vs
+  //                        13.8+ two-step).  With halos: two timesteps per pass (half the exchanges).
   //   1.5 .. 6 Mi cells  : two timesteps per pass, 2 cells per lane (93 VGPRs, 5 waves/SIMD: twice the
   //                        waves of the 4-cell form; 1280^2: 19.1 vs 21.2 us, 2048^2: 40 vs 51.5 (one-step))
   //   >= 6 Mi cells      : two timesteps per pass, 4 cells per lane (16-byte accesses; 8192^2: 517 us vs
@@ -741,7 +911,10 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
   for (int s = 0; s < n_slabs; s++)
     if ((long)params->nx * c->slab[s].rows < min_cells) min_cells = (long)params->nx * c->slab[s].rows;
   if (world > 1) min_cells = (long)params->nx * (params->ny / world);
-  c->fuse2 = (c->vec4 && env_int("LBM_FUSE2", min_cells >= 3L * 512 * 1024 ? 1 : 0)) ? 1 : 0;
+  // Across slabs / ranks a pass costs one exchange and ~10 runtime calls per slab whatever it computes, so
+  // two timesteps per pass always pay there (1024^2 over 2/4/8 slabs on one device: 45/74/97 us per step
+  // vs 70/113/125 one-step; 2048^2 over 8: 96 vs 261).
+  c->fuse2 = (c->vec4 && env_int("LBM_FUSE2", (min_cells >= 3L * 512 * 1024 || halo_on) ? 1 : 0)) ? 1 : 0;
   c->lane_cells = env_int("LBM_LANE_CELLS", min_cells >= 6L * 1024 * 1024 ? 4 : 2) == 2 ? 2 : 4;
   c->n_strips = ceil_div(params->nx / c->lane_cells > 0 ? params->nx / c->lane_cells : 1, lbm::kStripQuads);
   // Band height.  A wave sweeps band_rows + 2 rows.  4-cell form: 256 CUs x 12 waves are resident
@@ -900,7 +1073,16 @@ int lbm_get_info(const lbm_ctx* c, lbm_info* out) {
   out->math_mode = c->math_mode;
   out->world_rank = c->rank;
   out->world_size = c->world;
-  out->steps_per_launch = c->fuse2 ? 2 : 1;
+  const bool stale = (c->halo != HALO_SELF && c->halo_mode == LBM_HALO_STALE);
+  out->steps_per_launch = (c->fuse2 && !stale) ? 2 : 1;
+  out->halo_mode = c->halo_mode;
+  return LBM_SUCCESS;
+}
+
+int lbm_set_halo_mode(lbm_ctx* c, int mode) {
+  if (!c) LBM_FAIL(LBM_FAILURE, "lbm_set_halo_mode: null context");
+  if (mode != LBM_HALO_SYNC && mode != LBM_HALO_STALE) LBM_FAIL(LBM_FAILURE, "lbm_set_halo_mode: unknown mode %d", mode);
+  c->halo_mode = mode;
   return LBM_SUCCESS;
 }
 

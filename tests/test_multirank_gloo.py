@@ -36,13 +36,19 @@ import torch.multiprocessing as mp
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+def random_cells(p, seed):
+    rng = np.random.default_rng(seed)
+    w = np.array([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4, dtype=np.float32) * np.float32(p.density)
+    return (w * (1.0 + 0.05 * rng.standard_normal((p.ny, p.nx, 9)))).astype(np.float32)
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
 
 
-def rank_main(rank, world, port, name, steps, out_dir):
+def rank_main(rank, world, port, name, steps, out_dir, lag=0, seed=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -62,7 +68,8 @@ def rank_main(rank, world, port, name, steps, out_dir):
             if -1 <= loc <= rows:
                 lid_local = loc
 
-        full = np.ascontiguousarray(oracle.init_cells(p).transpose(2, 0, 1))      # (9, ny, nx)
+        start = oracle.init_cells(p) if seed is None else random_cells(p, seed)
+        full = np.ascontiguousarray(start.transpose(2, 0, 1))                     # (9, ny, nx)
         S = np.zeros((9, rows + 2 * H, p.nx), dtype=np.float32)                   # array row = local row + H
         S[:, H:H + rows] = full[:, first:first + rows]
         T = np.zeros_like(S)
@@ -96,20 +103,29 @@ def rank_main(rank, world, port, name, steps, out_dir):
             arr[:, H - depth:H] = recv_s.numpy()
             arr[:, H + rows:H + rows + depth] = recv_n.numpy()
 
-        t = 0
+        t, m, stale = 0, 0, None
         while t < steps:
-            two = t + 1 < steps
+            two = t + 1 < steps and not lag      # stale passes always advance one timestep
             depth = 2          # the engine ships both halo rows every pass once the two-step kernel is on
             # accelerate_flow of step t on the owned copy; the halo copies arrive already accelerated
             if lid_local is not None and 0 <= lid_local < rows:
                 accelerate(S, lid_local)
             reqs, recv_s, recv_n = exchange(S, depth)
-            if two:
-                # step t on the rows whose inputs are all owned (overlaps the exchange) ...
-                s_in = relax(S, T, 1, rows - 2)
-                for r in reqs:
-                    r.wait()
+            if lag and m > 0:
+                # stale-halo mode (run_steps_stale): this pass reads what the neighbours sent one pass
+                # ago; the exchange posted above only has to land before the NEXT pass
+                land(S, depth, *stale)
+            # step t on the rows whose inputs are all owned (overlaps the exchange) ...
+            s_in = relax(S, T, 1, rows - 2)
+            for r in reqs:
+                r.wait()
+            if lag:
+                if m == 0:
+                    land(S, depth, recv_s, recv_n)              # every run starts from fresh halos
+                stale = (recv_s.clone(), recv_n.clone())
+            else:
                 land(S, depth, recv_s, recv_n)
+            if two:
                 # ... then on rows -1, 0 and rows-1, rows (halo-dependent; -1 and rows redundantly)
                 relax(S, T, -1, -1)
                 s_b = relax(S, T, 0, 0) + relax(S, T, rows - 1, rows - 1)
@@ -122,13 +138,10 @@ def rank_main(rank, world, port, name, steps, out_dir):
                 S, U = U, S
                 t += 2
             else:
-                s_in = relax(S, T, 1, rows - 2)
-                for r in reqs:
-                    r.wait()
-                land(S, depth, recv_s, recv_n)
                 tot_u[t] = float(s_in) + float(relax(S, T, 0, 0)) + float(relax(S, T, rows - 1, rows - 1))
                 S, T = T, S
                 t += 1
+            m += 1
 
         tot = torch.from_numpy(tot_u)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -160,3 +173,28 @@ def test_row_sharded_ring_equals_single_domain(tmp_path, oracle, datasets, lbm, 
     got = np.load(tmp_path / "lattice.npy").transpose(1, 2, 0)
     assert np.array_equal(np.ascontiguousarray(got).view(np.uint32), ref.view(np.uint32))
     np.testing.assert_allclose(np.load(tmp_path / "av.npy"), ref_av, rtol=2e-4)
+
+
+@pytest.mark.parametrize("world,name,steps", [(2, "128x128", 23), (3, "128x256", 12)])
+def test_stale_halo_ring_equals_slab_model(tmp_path, oracle, datasets, lbm, world, name, steps):
+    """Stale-halo mode (lbm_set_halo_mode(LBM_HALO_STALE), the reproducible analogue of
+    /root/reference/MPI_Testall_OptimizedVersion/d2q9-bgk.c:256-301) over real message passing:
+    ranks that consume each exchange one pass late must reproduce tests/slab_model.py (lag = 1),
+    the model the GPU engine is held to bit for bit in tests/test_gpu_stale_halo.py.  A random start
+    makes every boundary cell sensitive to the lag."""
+    import slab_model
+    torch.set_num_threads(1)
+    mp.spawn(rank_main, args=(world, free_port(), name, steps, str(tmp_path), 1, 99), nprocs=world, join=True)
+    p, ob = datasets(name)
+    cells = random_cells(p, 99)
+    want, want_tot = slab_model.run_slabs(oracle, lbm, p, ob, [steps], world, lag=1, cells=cells)
+    got = np.ascontiguousarray(np.load(tmp_path / "lattice.npy").transpose(1, 2, 0))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    want_av = (want_tot / np.float64((ob == 0).sum())).astype(np.float32)
+    np.testing.assert_allclose(np.load(tmp_path / "av.npy"), want_av, rtol=2e-4)
+    # and the lag matters on this input: the synchronous protocol ends elsewhere
+    sync, _ = slab_model.run_slabs(oracle, lbm, p, ob, [steps], world, lag=0, cells=cells)
+    assert not np.array_equal(sync.view(np.uint32), want.view(np.uint32))
+    ref = cells.copy()
+    oracle.run(p, ref, ob, steps)
+    assert np.array_equal(sync.view(np.uint32), ref.view(np.uint32))      # the model itself is pinned
