@@ -167,9 +167,6 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
 
-    total_steps = args.warmup + args.steps
-    p, ob, workload = synthetic_case(lbm, nx, ny, total_steps)
-
     # LBM_BENCH_RANK_API=1 takes the one-process-per-GPU code path even for a world of one
     # (rehearsal of the torchrun path on a 1-GPU box)
     use_rank_api = world > 1 or os.environ.get("LBM_BENCH_RANK_API") == "1"
@@ -177,37 +174,67 @@ def main():
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
     if use_rank_api:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    def make_engine(p, ob):
+        if not use_rank_api:
+            return lbm.Engine(p, ob, None, n_gpus=1, math=args.math)
         uid = [lbm.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        eng = lbm.Engine(p, ob, None, math=args.math, rank=rank, world_size=world,
-                         unique_id=uid[0], device=local_rank)
-    else:
-        eng = lbm.Engine(p, ob, None, n_gpus=1, math=args.math)
+        return lbm.Engine(p, ob, None, math=args.math, rank=rank, world_size=world,
+                          unique_id=uid[0], device=local_rank)
 
-    def fence():
-        eng.sync()
-        torch.cuda.synchronize()
-        if use_rank_api:
-            dist.barrier()
+    def measure(gx, gy, steps, warmup):
+        """One timed run of `steps` timesteps of a gx x gy grid after `warmup` untimed ones: barrier +
+        device sync on both sides, max over ranks.  Returns (seconds, kernel ms per step,
+        steps_per_launch, av_vels finite, workload description)."""
+        p, ob, workload = synthetic_case(lbm, gx, gy, warmup + steps)
+        eng = make_engine(p, ob)
+
+        def fence():
+            eng.sync()
             torch.cuda.synchronize()
+            if use_rank_api:
+                dist.barrier()
+                torch.cuda.synchronize()
 
-    if args.warmup > 0:
-        eng.run(args.warmup)
-    fence()
-    t0 = time.perf_counter()
-    kernel_ms = eng.run_timed(args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
+        if warmup > 0:
+            eng.run(warmup)
+        fence()
+        t0 = time.perf_counter()
+        kernel_ms = eng.run_timed(steps)
+        fence()
+        elapsed = time.perf_counter() - t0
+        if use_rank_api:
+            t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed, kernel_ms = float(t[0]), float(t[1])
+        av = eng.av_vels(warmup + steps)          # forces the cross-rank reduce too
+        finite = bool(np.isfinite(av).all())
+        spl = eng.info()["steps_per_launch"]
+        eng.close()
+        return elapsed, kernel_ms, spl, finite, workload
 
-    if use_rank_api:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(t[0]), float(t[1])
+    elapsed, kernel_ms, steps_per_launch, finite, workload = measure(nx, ny, args.steps, args.warmup)
 
-    av = eng.av_vels(total_steps)          # forces the cross-rank reduce too
-    finite = bool(np.isfinite(av).all())
-    steps_per_launch = eng.info()["steps_per_launch"]
-    eng.close()
+    # BASELINE.json's other named configurations, measured the same way (every rank takes part):
+    # the reference's own 1024x1024 data set (20 000 steps in the reference; Infinity-Cache resident,
+    # so MLUPS only, no HBM figure; strong-scaling it over several GPUs is exchange-latency bound and
+    # reported as measured) and the 16384x16384 synthetic grid of the scaling configuration
+    also = {}
+    if os.environ.get("LBM_BENCH_ALSO", "1") != "0":
+        for (gx, gy, st, wu, note) in ((1024, 1024, 2000, 200, "reference data set 1024x1024, cache resident"),
+                                       (16384, 16384, 100, 10, "synthetic 16384x16384 (BASELINE.json configs[4])")):
+            if (gx, gy) == (nx, ny):
+                continue
+            try:
+                dt, k_ms, spl, fin, _ = measure(gx, gy, st, wu)
+                also[f"{gx}x{gy}"] = {"value": gx * gy * st / dt / 1e6, "unit": "MLUPS", "n_gpus": args.gpus,
+                                      "ms_per_step": dt / st * 1e3, "kernel_ms_per_step": k_ms, "steps": st,
+                                      "warmup": wu, "steps_per_launch": spl, "results_finite": fin, "note": note}
+            except Exception as exc:            # never lose the main line over an extra one
+                also[f"{gx}x{gy}"] = {"error": str(exc)}
+                if use_rank_api:
+                    break                       # ranks may have diverged: stop issuing collectives
 
     if rank == 0:
         cells = float(nx) * float(ny)
@@ -246,25 +273,8 @@ def main():
                          else "achieved = algorithmic bytes (72 B per lattice update) / launch time"},
             "results_finite": finite,
         }
-        if world == 1 and (nx, ny) != (1024, 1024):
-            # BASELINE.json's metric also names the reference's own 1024x1024 data set
-            # (20 000 steps in the reference; Infinity-Cache resident, so MLUPS only, no HBM figure)
-            try:
-                p2, ob2, _ = synthetic_case(lbm, 1024, 1024, 2200)
-                with lbm.Engine(p2, ob2, None, n_gpus=1, math=args.math) as e2:
-                    e2.run(200)
-                    e2.sync()
-                    t1 = time.perf_counter()
-                    k2 = e2.run_timed(2000)
-                    e2.sync()
-                    dt2 = time.perf_counter() - t1
-                    spl2 = e2.info()["steps_per_launch"]
-                line["also"] = {"1024x1024": {"value": 1024 * 1024 * 2000 / dt2 / 1e6, "unit": "MLUPS",
-                                              "ms_per_step": dt2 / 2000 * 1e3, "kernel_ms_per_step": k2,
-                                              "steps": 2000, "warmup": 200, "steps_per_launch": spl2,
-                                              "note": "reference data set 1024x1024, cache resident"}}
-            except Exception as exc:            # never lose the main line over the extra one
-                line["also"] = {"1024x1024": {"error": str(exc)}}
+        if also:
+            line["also"] = also
         if world == 1 and not args.no_cpu_baseline:
             base = cpu_baseline(nx, ny)
             if base:
