@@ -364,3 +364,20 @@ def test_run_beyond_record_fails(lbm, datasets):
         eng.run(5)
         with pytest.raises(lbm.LbmError):
             eng.run(1)
+
+
+@pytest.mark.parametrize("knob,value", [("LBM_NEIGH", "1"), ("LBM_NEIGH", "2"), ("LBM_SNAKE", "1"),
+                                        ("LBM_PLANE_PAD_FLOATS", "16"), ("LBM_NTS", "1"), ("LBM_NTS", "0"),
+                                        ("LBM_VEC4", "0"), ("LBM_VEC4", "1")])
+@pytest.mark.parametrize("fuse", ["0", "1"])
+def test_tuning_knobs_do_not_change_results(lbm, oracle, monkeypatch, knob, value, fuse):
+    """Every environment knob of DESIGN.md section 6a selects a different kernel flavour or layout, never a
+    different result: each one bit-exact against the oracle, single slab and across 3 slabs."""
+    monkeypatch.setenv("LBM_FUSE2", fuse)
+    monkeypatch.setenv("LBM_HALO", "memcpy")
+    monkeypatch.setenv(knob, value)
+    p, ob, cells = random_case(lbm, 320, 29, 41)
+    for slabs in (1, 3):
+        ref_cells, ref_av, got_cells, got_av, _ = run_both(lbm, oracle, p, ob, cells, 13, n_gpus=slabs)
+        assert np.array_equal(ref_cells.view(np.uint32), got_cells.view(np.uint32)), (knob, value, slabs)
+        np.testing.assert_allclose(got_av, ref_av, rtol=AV_RTOL)
