@@ -413,6 +413,34 @@ int flush_partials(lbm_ctx* c, int step_base) {
   });
 }
 
+// the slab threads spin between phases while a run is in flight
+struct HotGuard {
+  SlabTeam* t;
+  explicit HotGuard(SlabTeam* team) : t(team) { if (t) { t->hot.store(true); t->cv.notify_all(); } }
+  ~HotGuard() { if (t) t->hot.store(false); }
+};
+
+// device time per timestep between ev_t0 (recorded by the caller at the start of the run) and now, on
+// the compute streams the step kernels run on; max over slabs
+int read_step_timing(lbm_ctx* c, int n_steps, float* kernel_ms) {
+  float worst = 0.f;
+  for (int s = 0; s < c->n_slabs; s++) {
+    Slab& sl = c->slab[s];
+    HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+    HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_t1, sl.compute));
+  }
+  for (int s = 0; s < c->n_slabs; s++) {
+    Slab& sl = c->slab[s];
+    HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+    HIP_TRY(LBM_FAILURE, hipEventSynchronize(sl.ev_t1));
+    float ms = 0.f;
+    HIP_TRY(LBM_FAILURE, hipEventElapsedTime(&ms, sl.ev_t0, sl.ev_t1));
+    if (ms > worst) worst = ms;
+  }
+  *kernel_ms = worst / (float)n_steps;
+  return LBM_SUCCESS;
+}
+
 // The timestep loop.  Single slab: one fused launch per pass (one or two timesteps).  Several slabs / ranks
 // (the Waitall pattern of MPI_Waitall/d2q9-bgk.c:225-253, restructured for two HIP streams):
 //
@@ -443,12 +471,7 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
   const float a1 = c->p.density * c->p.accel / 9.f;
   const float a2 = c->p.density * c->p.accel / 36.f;
   const bool halo = (c->halo != HALO_SELF);
-  // the slab threads spin between phases while the run is in flight
-  struct HotGuard {
-    SlabTeam* t;
-    explicit HotGuard(SlabTeam* team) : t(team) { if (t) { t->hot.store(true); t->cv.notify_all(); } }
-    ~HotGuard() { if (t) t->hot.store(false); }
-  } hot_guard(c->team);
+  HotGuard hot_guard(c->team);
 
   // accelerate_flow() of the first step (later steps: epilogue of the step kernel)
   if (for_slabs(c, [&](int s) -> int {
@@ -546,24 +569,7 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
   c->steps_done += n_steps;
   // (the last flush made every compute stream wait for its final boundary kernel)
 
-  if (kernel_ms) {
-    float worst = 0.f;
-    for (int s = 0; s < c->n_slabs; s++) {
-      Slab& sl = c->slab[s];
-      HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
-      HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_t1, sl.compute));
-    }
-    for (int s = 0; s < c->n_slabs; s++) {
-      Slab& sl = c->slab[s];
-      HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
-      HIP_TRY(LBM_FAILURE, hipEventSynchronize(sl.ev_t1));
-      float ms = 0.f;
-      HIP_TRY(LBM_FAILURE, hipEventElapsedTime(&ms, sl.ev_t0, sl.ev_t1));
-      if (ms > worst) worst = ms;
-    }
-    *kernel_ms = worst / (float)n_steps;
-  }
-  return LBM_SUCCESS;
+  return kernel_ms ? read_step_timing(c, n_steps, kernel_ms) : LBM_SUCCESS;
 }
 
 // Stale-halo ("asynchronous") timestep loop: the GPU analogue of the reference's research variant,
@@ -592,11 +598,7 @@ int run_steps_stale(lbm_ctx* c, int n_steps, float* kernel_ms) {
   const float a1 = c->p.density * c->p.accel / 9.f;
   const float a2 = c->p.density * c->p.accel / 36.f;
   const int depth = 1;  // one timestep per pass (see above): only the adjacent row is read
-  struct HotGuard {
-    SlabTeam* t;
-    explicit HotGuard(SlabTeam* team) : t(team) { if (t) { t->hot.store(true); t->cv.notify_all(); } }
-    ~HotGuard() { if (t) t->hot.store(false); }
-  } hot_guard(c->team);
+  HotGuard hot_guard(c->team);
 
   // accelerate_flow() of the first step, then fresh halos for pass 0 (same lattice) and, from the same
   // rows, the one-pass-old halos of pass 1 (other lattice)
@@ -618,11 +620,8 @@ int run_steps_stale(lbm_ctx* c, int n_steps, float* kernel_ms) {
   if (exchange_halos(c, depth, c->cur, c->cur ^ 1, 0) != LBM_SUCCESS) return LBM_FAILURE;  // read by S(1)
 
   int flushed_upto = c->steps_done;
-  int m = 0;
-  for (int t = 0; t < n_steps; m++) {
-    const bool two = false;
-    const int adv = 1;
-    const bool last = (t + adv == n_steps);
+  for (int m = 0; m < n_steps; m++) {  // pass m = timestep m of this call
+    const bool last = (m + 1 == n_steps);
     const int slot = (m + 1) & 1;  // the exchange S(m) consumes: issued during pass m-2 (or the prologue)
     if (for_slabs(c, [&](int s) -> int {
           Slab& sl = c->slab[s];
@@ -636,25 +635,15 @@ int run_steps_stale(lbm_ctx* c, int n_steps, float* kernel_ms) {
             HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, c->slab[north].ev_x[slot], 0));
             HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, c->slab[south].ev_x[slot], 0));
           }
-          if (two) {
-            if (launch_step2(c, s, sl.compute, 0, sl.rows, c->band_rows, c->band_rows, ceil_div(sl.rows, c->band_rows), 0,
-                             !last) != LBM_SUCCESS)
-              return LBM_FAILURE;
-          } else {
-            if (launch_step(c, s, sl.compute, 0, 1, sl.rows, 0, !last) != LBM_SUCCESS) return LBM_FAILURE;
-          }
+          if (launch_step(c, s, sl.compute, 0, 1, sl.rows, 0, !last) != LBM_SUCCESS) return LBM_FAILURE;
           HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_step, sl.compute));
           return LBM_SUCCESS;
         }) != LBM_SUCCESS)
       return LBM_FAILURE;
-    for (int s = 0; s < c->n_slabs; s++) {
-      Slab& sl = c->slab[s];
-      const int n_part = two ? c->n_strips * ceil_div(sl.rows, c->band_rows) : blocks_for_rows(c, sl.rows);
-      for (int k = 0; k < adv; k++) sl.slot_counts.n[c->slot_fill + k] = n_part;
-    }
+    for (int s = 0; s < c->n_slabs; s++)
+      c->slab[s].slot_counts.n[c->slot_fill] = blocks_for_rows(c, c->slab[s].rows);
     c->cur ^= 1;
-    c->slot_fill += adv;
-    t += adv;
+    c->slot_fill += 1;
     // X'(m+1): the rows S(m) just produced, for S(m+2)
     if (!last && exchange_halos(c, depth, c->cur, c->cur ^ 1, slot) != LBM_SUCCESS) return LBM_FAILURE;
     if (c->slot_fill >= kPartSlots - 1 || last) {
@@ -671,24 +660,7 @@ int run_steps_stale(lbm_ctx* c, int n_steps, float* kernel_ms) {
     HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
     for (int i = 0; i < 2; i++) HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, sl.ev_x[i], 0));
   }
-  if (kernel_ms) {
-    float worst = 0.f;
-    for (int s = 0; s < c->n_slabs; s++) {
-      Slab& sl = c->slab[s];
-      HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
-      HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_t1, sl.compute));
-    }
-    for (int s = 0; s < c->n_slabs; s++) {
-      Slab& sl = c->slab[s];
-      HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
-      HIP_TRY(LBM_FAILURE, hipEventSynchronize(sl.ev_t1));
-      float ms = 0.f;
-      HIP_TRY(LBM_FAILURE, hipEventElapsedTime(&ms, sl.ev_t0, sl.ev_t1));
-      if (ms > worst) worst = ms;
-    }
-    *kernel_ms = worst / (float)n_steps;
-  }
-  return LBM_SUCCESS;
+  return kernel_ms ? read_step_timing(c, n_steps, kernel_ms) : LBM_SUCCESS;
 }
 
 void free_slab(Slab& sl) {
@@ -992,8 +964,6 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
   return c;
 }
 
-// copy rows [0, rows) of slab s out through a staging buffer with `kernel` producing `per_cell`
-// floats per cell
 }  // namespace
 
 // ================================================================================================
