@@ -902,7 +902,11 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
     const long resident = 256L * 4 * (c->lane_cells == 4 ? 3 : 5);  // waves resident at once
     const long slab_rows = (n_slabs > 1 || world > 1) ? (c->row_count / n_slabs) - 4 : c->row_count;
     const long rows_eff = slab_rows > 1 ? slab_rows : 1;
-    if ((long)c->n_strips * ceil_div(rows_eff, 8) < 5 * resident) {
+    // (in the interior/boundary pipeline of a multi-slab run the 4-cell form keeps the short bands:
+    // one rank's share of 8192^2 through the rank pipeline, us per step at band 6-7 vs the round
+    // model's pick: 8192x2048 139 vs 149, 8192x1024 77-78 vs 79-82, 8192x4096 251-258 either way)
+    const bool round_model = !(halo_on && c->lane_cells == 4);
+    if (round_model && (long)c->n_strips * ceil_div(rows_eff, 8) < 5 * resident) {
       const long lo = (c->lane_cells == 4) ? 4 : 3;
       long best_cost = -1;
       for (int k = 1; k <= 4; k++) {
