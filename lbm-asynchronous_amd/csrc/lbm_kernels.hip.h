@@ -186,7 +186,7 @@ __device__ __forceinline__ float div_with_rcp(float a, float b, float r) {
   e = __fmaf_rn(-b, q, a);
   return __fmaf_rn(e, r, q);
 }
-// density and velocity as moments_exact; false when the density forced the IEEE divides
+// density and velocity with the bits of moments_exact, the two divides sharing one refined reciprocal
 __device__ __forceinline__ void moments_shared(const float (&f)[kQ], float& rho, float& ux, float& uy) {
   float d = f[0];
 #pragma unroll
@@ -439,7 +439,8 @@ __global__ __launch_bounds__(BLOCK) void step_vec4(const StepArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// TWO timesteps per pass over memory (temporal blocking), single slab, periodic in x and y.
+// TWO timesteps per pass over memory (temporal blocking); periodic in x, in y either periodic (single
+// slab) or fed by the two halo rows stored below and above a slab (wrap = 0).
 //
 // The one-step kernel above sits at the float4-copy ceiling of the chip (72 B per update cannot
 // move faster).  The only way past that roofline is to move fewer bytes: this kernel advances the
