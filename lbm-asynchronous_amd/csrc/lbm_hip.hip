@@ -8,6 +8,7 @@
 #include "lbm_kernels.hip.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <rccl/rccl.h>
 
 #include <atomic>
@@ -211,8 +212,10 @@ int for_slabs(lbm_ctx* c, const std::function<int(int)>& body) {
 }
 
 // ---- launch helpers --------------------------------------------------------------------------
+// `done` (optional): event bound to the kernel's own completion signal (hipExtLaunchKernel's stop event)
+// -- what hipEventRecord right after the launch would mark, without a barrier packet of its own
 int launch_step(lbm_ctx* c, int s, hipStream_t stream, int row_first, int row_stride, int n_rows,
-                int part_offset, bool accel_epilogue) {
+                int part_offset, bool accel_epilogue, hipEvent_t done = nullptr) {
   Slab& sl = c->slab[s];
   if (n_rows <= 0) return LBM_SUCCESS;
   lbm::StepArgs a;
@@ -247,11 +250,12 @@ int launch_step(lbm_ctx* c, int s, hipStream_t stream, int row_first, int row_st
         {{lbm::step_vec4<1, 0, false>, lbm::step_vec4<1, 0, true>},
          {lbm::step_vec4<1, 1, false>, lbm::step_vec4<1, 1, true>},
          {lbm::step_vec4<1, 2, false>, lbm::step_vec4<1, 2, true>}}};
-    hipLaunchKernelGGL(table[exact ? 0 : 1][c->neigh][c->nts], dim3(blocks), dim3(lbm::kBlock), 0, stream, a);
+    hipExtLaunchKernelGGL(table[exact ? 0 : 1][c->neigh][c->nts], dim3(blocks), dim3(lbm::kBlock), 0, stream, nullptr,
+                          done, 0, a);
   } else {
     const int blocks = ceil_div((long)c->p.nx * n_rows, lbm::kBlock);
-    if (exact) hipLaunchKernelGGL(lbm::step_scalar<true>, dim3(blocks), dim3(lbm::kBlock), 0, stream, a);
-    else       hipLaunchKernelGGL(lbm::step_scalar<false>, dim3(blocks), dim3(lbm::kBlock), 0, stream, a);
+    hipExtLaunchKernelGGL(exact ? lbm::step_scalar<true> : lbm::step_scalar<false>, dim3(blocks), dim3(lbm::kBlock), 0,
+                          stream, nullptr, done, 0, a);
   }
   HIP_TRY(LBM_FAILURE, hipGetLastError());
   return LBM_SUCCESS;
@@ -261,7 +265,7 @@ int launch_step(lbm_ctx* c, int s, hipStream_t stream, int row_first, int row_st
 // band_rows rows that start band_pitch rows apart; writes the partials of steps t and t+1 into
 // slots slot_fill and slot_fill+1
 int launch_step2(lbm_ctx* c, int s, hipStream_t stream, int row_first, int row_end, int band_rows,
-                 int band_pitch, int band_count, int part_offset, bool accel_after) {
+                 int band_pitch, int band_count, int part_offset, bool accel_after, hipEvent_t done = nullptr) {
   Slab& sl = c->slab[s];
   if (band_count <= 0) return LBM_SUCCESS;
   lbm::Step2Args a;
@@ -294,8 +298,8 @@ int launch_step2(lbm_ctx* c, int s, hipStream_t stream, int row_first, int row_e
        {lbm::step2_stream<0, true, 4>, lbm::step2_stream<0, true, 2>}},
       {{lbm::step2_stream<1, false, 4>, lbm::step2_stream<1, false, 2>},
        {lbm::step2_stream<1, true, 4>, lbm::step2_stream<1, true, 2>}}};
-  hipLaunchKernelGGL(table[c->math_mode == LBM_MATH_EXACT ? 0 : 1][c->nts][c->lane_cells == 2 ? 1 : 0], dim3(waves),
-                     dim3(64), 0, stream, a);
+  hipExtLaunchKernelGGL(table[c->math_mode == LBM_MATH_EXACT ? 0 : 1][c->nts][c->lane_cells == 2 ? 1 : 0], dim3(waves),
+                        dim3(64), 0, stream, nullptr, done, 0, a);
   HIP_TRY(LBM_FAILURE, hipGetLastError());
   return LBM_SUCCESS;
 }
@@ -511,17 +515,19 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
           Slab& sl = c->slab[s];
           HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
           if (halo && m > 0) HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, sl.ev_boundary, 0));  // B(m-1)
+          static const int ext_events = env_int("LBM_EXT_EVENTS", 1);
+          hipEvent_t done = (halo && ext_events) ? sl.ev_interior[m & 1] : nullptr;  // I(m) done
           if (two) {
             const int r0 = halo ? 2 : 0, r1 = halo ? sl.rows - 2 : sl.rows;
             if (launch_step2(c, s, sl.compute, r0, r1, c->band_rows, c->band_rows, ceil_div(r1 - r0, c->band_rows), 0,
-                             !last) != LBM_SUCCESS)
+                             !last, done) != LBM_SUCCESS)
               return LBM_FAILURE;
           } else if (!halo) {
             if (launch_step(c, s, sl.compute, 0, 1, sl.rows, 0, !last) != LBM_SUCCESS) return LBM_FAILURE;
           } else {
-            if (launch_step(c, s, sl.compute, 1, 1, sl.rows - 2, 0, !last) != LBM_SUCCESS) return LBM_FAILURE;
+            if (launch_step(c, s, sl.compute, 1, 1, sl.rows - 2, 0, !last, done) != LBM_SUCCESS) return LBM_FAILURE;
           }
-          if (halo) HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_interior[m & 1], sl.compute));
+          if (halo && !done) HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_interior[m & 1], sl.compute));
           return LBM_SUCCESS;
         }) != LBM_SUCCESS)
       return LBM_FAILURE;
@@ -536,14 +542,16 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
             HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, c->slab[north].ev_halo, 0));
             HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, c->slab[south].ev_halo, 0));
           }
+          static const int ext_events_b = env_int("LBM_EXT_EVENTS", 1);
+          hipEvent_t bdone = ext_events_b ? sl.ev_boundary : nullptr;  // B(m) done
           if (two) {
             // rows 0,1 and rows-2,rows-1 as two 2-row bands in one launch
             const int off = c->n_strips * ceil_div(sl.rows - 4, c->band_rows);
-            if (launch_step2(c, s, sl.comm, 0, sl.rows, 2, sl.rows - 2, 2, off, !last) != LBM_SUCCESS) return LBM_FAILURE;
+            if (launch_step2(c, s, sl.comm, 0, sl.rows, 2, sl.rows - 2, 2, off, !last, bdone) != LBM_SUCCESS) return LBM_FAILURE;
           } else {
-            if (launch_step(c, s, sl.comm, 0, sl.rows - 1, 2, sl.blocks_main, !last) != LBM_SUCCESS) return LBM_FAILURE;
+            if (launch_step(c, s, sl.comm, 0, sl.rows - 1, 2, sl.blocks_main, !last, bdone) != LBM_SUCCESS) return LBM_FAILURE;
           }
-          HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_boundary, sl.comm));
+          if (!bdone) HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_boundary, sl.comm));
           return LBM_SUCCESS;
         }) != LBM_SUCCESS)
       return LBM_FAILURE;
