@@ -154,8 +154,11 @@ __device__ __forceinline__ void collide_exact_body(const float (&t)[kQ], float o
   for (int k = 0; k < kQ; k++) r[k] = t[k] + omega * (eq[k] - t[k]);
 }
 
+// want_speed (wave-uniform): also return |u| of the relaxed cell for the av_velocity sum; the warm-up rows
+// of a two-step band relax cells whose |u| belongs to another band's sum
 template <bool EXACT>
-__device__ __forceinline__ void collide(const float (&t)[kQ], float omega, float (&r)[kQ], float& speed);
+__device__ __forceinline__ void collide(const float (&t)[kQ], float omega, float (&r)[kQ], float& speed,
+                                        bool want_speed = true);
 
 // ---- the two divides by the density, sharing one reciprocal -----------------------------------
 // hipcc expands the IEEE fp32 divide a / b (AMDGPU LowerFDIV32) into
@@ -206,7 +209,7 @@ __device__ __forceinline__ void moments_shared(const float (&f)[kQ], float& rho,
 
 template <>
 __device__ __forceinline__ void collide<true>(const float (&t)[kQ], float omega, float (&r)[kQ],
-                                              float& speed) {
+                                              float& speed, bool want_speed) {
   float rho, ux, uy;
   moments_shared(t, rho, ux, uy);
   // |u|^2 below 5e28 bounds every dividend of the fast constant divides (squares of ux, uy,
@@ -215,16 +218,19 @@ __device__ __forceinline__ void collide<true>(const float (&t)[kQ], float omega,
   if (ok) collide_exact_body<true>(t, omega, rho, ux, uy, r);
   else    collide_exact_body<false>(t, omega, rho, ux, uy, r);
   // av_velocity() looks at the relaxed populations (SerialCode/d2q9-bgk.c:169, 426-450)
-  float rho2, ux2, uy2;
-  moments_shared(r, rho2, ux2, uy2);
-  speed = sqrtf((ux2 * ux2) + (uy2 * uy2));  // IEEE: __fsqrt_rn is the native approximation
+  speed = 0.f;
+  if (want_speed) {
+    float rho2, ux2, uy2;
+    moments_shared(r, rho2, ux2, uy2);
+    speed = sqrtf((ux2 * ux2) + (uy2 * uy2));  // IEEE: __fsqrt_rn is the native approximation
+  }
 }
 
 // FAST: one reciprocal, multiplies by 3, 4.5, 1.5 and explicit FMAs.  BGK conserves density and
 // momentum, so |u| of the relaxed cell is taken from the pre-collision moments.
 template <>
 __device__ __forceinline__ void collide<false>(const float (&t)[kQ], float omega, float (&r)[kQ],
-                                               float& speed) {
+                                               float& speed, bool /*want_speed*/) {
   const float rho = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7])) + t[8];
   const float inv = 1.f / rho;
   const float ux = ((t[1] + t[5] + t[8]) - (t[3] + t[6] + t[7])) * inv;
@@ -488,13 +494,13 @@ constexpr int kStripQuads = 62;  // output lanes per wave (lanes 1..62; each own
 
 template <int MATH>
 __device__ __forceinline__ void relax_cell(const float (&t)[kQ], bool blocked, bool lid, float omega, float a1,
-                                           float a2, float (&r)[kQ], float& speed) {
+                                           float a2, float (&r)[kQ], float& speed, bool want_speed = true) {
   speed = 0.f;
   if (blocked) {
     bounce(t, r);
   } else {
-    if constexpr (MATH == 0) collide<true>(t, omega, r, speed);
-    else collide<false>(t, omega, r, speed);
+    if constexpr (MATH == 0) collide<true>(t, omega, r, speed, want_speed);
+    else collide<false>(t, omega, r, speed, want_speed);
     if (lid) accelerate(r, a1, a2);
   }
 }
@@ -601,7 +607,7 @@ __global__ __launch_bounds__(64) void step2_stream(const Step2Args a) {
 #pragma unroll
     for (int j = 0; j < C; j++) {
       float speed;
-      relax_cell<MATH>(t[j], ((p.m >> (8 * j)) & 0xffu) != 0, lid, a.omega, a.a1, a.a2, N[j], speed);
+      relax_cell<MATH>(t[j], ((p.m >> (8 * j)) & 0xffu) != 0, lid, a.omega, a.a1, a.a2, N[j], speed, own_row);
       if (own_row && out_lane) sum1 += speed;
     }
 
