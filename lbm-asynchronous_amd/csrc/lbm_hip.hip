@@ -84,6 +84,8 @@ struct Slab {
   float* partials = nullptr;  // kPartSlots x part_stride
   double* tot_u = nullptr;    // capacity entries: per-step sum of |u| over this slab
   double* scratch = nullptr;  // 2 x kSumBlocks doubles for lattice_sums
+  int* flushed_dev = nullptr; // graph replay: index of the first step of the chunk being reduced
+  hipGraphExec_t chunk_graph[2] = {nullptr, nullptr};  // kPartSlots timesteps + their reduce, by lattice parity
   hipStream_t compute = nullptr, comm = nullptr;
   hipEvent_t ev_boundary = nullptr, ev_halo = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
   hipEvent_t ev_interior[2] = {nullptr, nullptr};  // interior kernel of step t -> [t & 1]
@@ -199,6 +201,7 @@ struct lbm_ctx {
   int band_rows = 8, n_strips = 0;  // step2_stream geometry: band height, waves across x
   int lane_cells = 4;               // cells per lane in step2_stream (4 or 2; LBM_LANE_CELLS)
   SlabTeam* team = nullptr;         // one issuing thread per slab (one-process multi-GPU), or null
+  int use_graph = 0;                // single slab: replay kPartSlots timesteps + reduce as one hipGraph
 };
 
 namespace {
@@ -250,12 +253,14 @@ int launch_step(lbm_ctx* c, int s, hipStream_t stream, int row_first, int row_st
         {{lbm::step_vec4<1, 0, false>, lbm::step_vec4<1, 0, true>},
          {lbm::step_vec4<1, 1, false>, lbm::step_vec4<1, 1, true>},
          {lbm::step_vec4<1, 2, false>, lbm::step_vec4<1, 2, true>}}};
-    hipExtLaunchKernelGGL(table[exact ? 0 : 1][c->neigh][c->nts], dim3(blocks), dim3(lbm::kBlock), 0, stream, nullptr,
-                          done, 0, a);
+    if (done) hipExtLaunchKernelGGL(table[exact ? 0 : 1][c->neigh][c->nts], dim3(blocks), dim3(lbm::kBlock), 0, stream,
+                                    nullptr, done, 0, a);
+    else hipLaunchKernelGGL(table[exact ? 0 : 1][c->neigh][c->nts], dim3(blocks), dim3(lbm::kBlock), 0, stream, a);
   } else {
     const int blocks = ceil_div((long)c->p.nx * n_rows, lbm::kBlock);
-    hipExtLaunchKernelGGL(exact ? lbm::step_scalar<true> : lbm::step_scalar<false>, dim3(blocks), dim3(lbm::kBlock), 0,
-                          stream, nullptr, done, 0, a);
+    const auto fn = exact ? lbm::step_scalar<true> : lbm::step_scalar<false>;
+    if (done) hipExtLaunchKernelGGL(fn, dim3(blocks), dim3(lbm::kBlock), 0, stream, nullptr, done, 0, a);
+    else hipLaunchKernelGGL(fn, dim3(blocks), dim3(lbm::kBlock), 0, stream, a);
   }
   HIP_TRY(LBM_FAILURE, hipGetLastError());
   return LBM_SUCCESS;
@@ -298,8 +303,9 @@ int launch_step2(lbm_ctx* c, int s, hipStream_t stream, int row_first, int row_e
        {lbm::step2_stream<0, true, 4>, lbm::step2_stream<0, true, 2>}},
       {{lbm::step2_stream<1, false, 4>, lbm::step2_stream<1, false, 2>},
        {lbm::step2_stream<1, true, 4>, lbm::step2_stream<1, true, 2>}}};
-  hipExtLaunchKernelGGL(table[c->math_mode == LBM_MATH_EXACT ? 0 : 1][c->nts][c->lane_cells == 2 ? 1 : 0], dim3(waves),
-                        dim3(64), 0, stream, nullptr, done, 0, a);
+  const fn kernel = table[c->math_mode == LBM_MATH_EXACT ? 0 : 1][c->nts][c->lane_cells == 2 ? 1 : 0];
+  if (done) hipExtLaunchKernelGGL(kernel, dim3(waves), dim3(64), 0, stream, nullptr, done, 0, a);
+  else hipLaunchKernelGGL(kernel, dim3(waves), dim3(64), 0, stream, a);
   HIP_TRY(LBM_FAILURE, hipGetLastError());
   return LBM_SUCCESS;
 }
@@ -406,7 +412,7 @@ int flush_partials(lbm_ctx* c, int step_base) {
     const bool split = (c->halo != HALO_SELF && c->halo_mode == LBM_HALO_SYNC);
     if (split) HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, sl.ev_boundary, 0));
     hipLaunchKernelGGL(lbm::reduce_partials, dim3(c->slot_fill), dim3(lbm::kBlock), 0, sl.compute,
-                       sl.partials, sl.slot_counts, c->part_stride, sl.tot_u, step_base);
+                       sl.partials, sl.slot_counts, c->part_stride, sl.tot_u, step_base, (const int*)nullptr);
     HIP_TRY(LBM_FAILURE, hipGetLastError());
     if (split) {
       // the next boundary kernels (comm stream) reuse the partial slots just read
@@ -415,6 +421,62 @@ int flush_partials(lbm_ctx* c, int step_base) {
     }
     return LBM_SUCCESS;
   });
+}
+
+// ---- hipGraph replay of the launch-bound loop (single periodic slab) ----------------------------------
+// kPartSlots timesteps and the reduce of their partial sums are captured once per lattice parity and
+// replayed with one hipGraphLaunch each.  All launch arguments of a chunk are the same every time
+// (an even number of passes returns to the same lattice, the partial slots are reused) except the index
+// of the chunk's first step in tot_u, which the reduce kernel reads from device memory.  Every pass
+// of a chunk applies the next step's acceleration, so a chunk is only replayed while at least one more
+// timestep follows it in the same lbm_run call.
+int capture_chunk(lbm_ctx* c, hipGraphExec_t* out) {
+  Slab& sl = c->slab[0];
+  const int saved_cur = c->cur, saved_fill = c->slot_fill;
+  hipGraph_t graph = nullptr;
+  HIP_TRY(LBM_FAILURE, hipStreamBeginCapture(sl.compute, hipStreamCaptureModeThreadLocal));
+  int rc = LBM_SUCCESS;
+  c->slot_fill = 0;
+  for (int t = 0; t < kPartSlots && rc == LBM_SUCCESS;) {
+    const int adv = c->fuse2 ? 2 : 1;
+    rc = c->fuse2 ? launch_step2(c, 0, sl.compute, 0, sl.rows, c->band_rows, c->band_rows,
+                                 ceil_div(sl.rows, c->band_rows), 0, true)
+                  : launch_step(c, 0, sl.compute, 0, 1, sl.rows, 0, true);
+    const int n_part = c->fuse2 ? c->n_strips * ceil_div(sl.rows, c->band_rows) : sl.blocks_main;
+    for (int k = 0; k < adv; k++) sl.slot_counts.n[c->slot_fill + k] = n_part;
+    c->cur ^= 1;
+    c->slot_fill += adv;
+    t += adv;
+  }
+  if (rc == LBM_SUCCESS) {
+    hipLaunchKernelGGL(lbm::reduce_partials, dim3(kPartSlots), dim3(lbm::kBlock), 0, sl.compute, sl.partials,
+                       sl.slot_counts, c->part_stride, sl.tot_u, 0, (const int*)sl.flushed_dev);
+    hipLaunchKernelGGL(lbm::advance_counter, dim3(1), dim3(1), 0, sl.compute, sl.flushed_dev, kPartSlots);
+  }
+  const hipError_t end = hipStreamEndCapture(sl.compute, &graph);
+  c->cur = saved_cur;  // an even number of passes
+  c->slot_fill = saved_fill;
+  if (rc != LBM_SUCCESS) { if (graph) (void)hipGraphDestroy(graph); return LBM_FAILURE; }
+  HIP_TRY(LBM_FAILURE, end);
+  const hipError_t inst = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  HIP_TRY(LBM_FAILURE, inst);
+  return LBM_SUCCESS;
+}
+
+// replays as many whole chunks as fit in front of the last timestep of this call; returns the timesteps done
+int replay_chunks(lbm_ctx* c, int n_steps, int first_step, int* done) {
+  *done = 0;
+  Slab& sl = c->slab[0];
+  const int n_chunks = (n_steps - 1) / kPartSlots;
+  if (n_chunks <= 0 || c->slot_fill != 0) return LBM_SUCCESS;
+  hipGraphExec_t& exec = sl.chunk_graph[c->cur];
+  if (!exec && capture_chunk(c, &exec) != LBM_SUCCESS) return LBM_FAILURE;
+  hipLaunchKernelGGL(lbm::set_counter, dim3(1), dim3(1), 0, sl.compute, sl.flushed_dev, first_step);
+  HIP_TRY(LBM_FAILURE, hipGetLastError());
+  for (int k = 0; k < n_chunks; k++) HIP_TRY(LBM_FAILURE, hipGraphLaunch(exec, sl.compute));
+  *done = n_chunks * kPartSlots;
+  return LBM_SUCCESS;
 }
 
 // the slab threads spin between phases while a run is in flight
@@ -505,8 +567,13 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
 
   // macro steps: two timesteps per pass where enabled and at least two remain, else one
   int flushed_upto = c->steps_done;
+  int t_first = 0;
+  if (!halo && c->use_graph) {
+    if (replay_chunks(c, n_steps, flushed_upto, &t_first) != LBM_SUCCESS) return LBM_FAILURE;
+    flushed_upto += t_first;
+  }
   int m = 0;  // macro step counter (event parity)
-  for (int t = 0; t < n_steps; m++) {
+  for (int t = t_first; t < n_steps; m++) {
     const bool two = c->fuse2 && (t + 1 < n_steps);
     const int adv = two ? 2 : 1;
     const bool last = (t + adv == n_steps);
@@ -679,6 +746,8 @@ void free_slab(Slab& sl) {
   if (sl.partials) (void)hipFree(sl.partials);
   if (sl.tot_u) (void)hipFree(sl.tot_u);
   if (sl.scratch) (void)hipFree(sl.scratch);
+  if (sl.flushed_dev) (void)hipFree(sl.flushed_dev);
+  for (int i = 0; i < 2; i++) if (sl.chunk_graph[i]) (void)hipGraphExecDestroy(sl.chunk_graph[i]);
   if (sl.ev_boundary) (void)hipEventDestroy(sl.ev_boundary);
   if (sl.ev_halo) (void)hipEventDestroy(sl.ev_halo);
   for (int i = 0; i < 2; i++) if (sl.ev_interior[i]) (void)hipEventDestroy(sl.ev_interior[i]);
@@ -727,6 +796,7 @@ int build_slab(lbm_ctx* c, int s, const int* obstacles, const float* cells_aos) 
   HIP_TRY(LBM_FAILURE, hipMalloc(&sl.tot_u, (size_t)(c->capacity > 0 ? c->capacity : 1) * sizeof(double)));
   HIP_TRY(LBM_FAILURE, hipMemsetAsync(sl.tot_u, 0, (size_t)(c->capacity > 0 ? c->capacity : 1) * sizeof(double), sl.compute));
   HIP_TRY(LBM_FAILURE, hipMalloc(&sl.scratch, 2 * kSumBlocks * sizeof(double)));
+  HIP_TRY(LBM_FAILURE, hipMalloc(&sl.flushed_dev, sizeof(int)));
 
   // obstacle mask: int (reference host type, SerialCode/d2q9-bgk.c:541) -> uint8 (rows+2) x pitch,
   // with the (periodic) neighbour rows -1 and `rows` so that a slab can relax its halo rows
@@ -810,6 +880,9 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
   const double lattice_pair_bytes = 2.0 * 36.0 * (double)params->nx * (double)params->ny;
   c->nts = env_int("LBM_NTS", lattice_pair_bytes > 512.0 * 1024 * 1024 ? 1 : 0) ? 1 : 0;
   c->snake = env_int("LBM_SNAKE", 0) ? 1 : 0;
+  // hipGraph replay pays where the loop is bound by the host's launch rate (~3.5 us per launch): measured
+  // 128^2 3.11 vs 3.52 us per step, 128x256 3.22 vs 3.53; no difference from 256^2 on
+  c->use_graph = env_int("LBM_GRAPH", (long)params->nx * params->ny < 64L * 1024 ? 1 : 0) ? 1 : 0;
   c->n_slabs = n_slabs;
 
   // rows of this context, then of each slab

@@ -741,10 +741,13 @@ constexpr int kPartSlotsMax = 64;
 struct SlotCounts {
   int n[kPartSlotsMax];  // valid partials in each slot (launch geometries differ between kernels)
 };
+// base_dev (optional): the first step's index is read from device memory, so that a captured hipGraph can be
+// replayed for later steps (advance_counter moves it on)
 __global__ __launch_bounds__(kBlock) void reduce_partials(const float* partials, SlotCounts counts,
                                                           long slot_stride, double* tot_u,
-                                                          int step_base) {
+                                                          int step_base, const int* base_dev) {
   __shared__ double sh[kBlock];
+  if (base_dev) step_base += *base_dev;
   const float* p = partials + (long)blockIdx.x * slot_stride;
   const int n_part = counts.n[blockIdx.x];
   double acc = 0.0;
@@ -757,6 +760,9 @@ __global__ __launch_bounds__(kBlock) void reduce_partials(const float* partials,
   }
   if (threadIdx.x == 0) tot_u[step_base + blockIdx.x] = sh[0];
 }
+
+__global__ void set_counter(int* p, int value) { *p = value; }
+__global__ void advance_counter(int* p, int by) { *p += by; }
 
 // uniform equilibrium start (SerialCode/d2q9-bgk.c:546-567)
 __global__ void init_equilibrium(float* lat, long ps, long row_pitch, int nx, int rows, float r0,

@@ -381,3 +381,22 @@ def test_tuning_knobs_do_not_change_results(lbm, oracle, monkeypatch, knob, valu
         ref_cells, ref_av, got_cells, got_av, _ = run_both(lbm, oracle, p, ob, cells, 13, n_gpus=slabs)
         assert np.array_equal(ref_cells.view(np.uint32), got_cells.view(np.uint32)), (knob, value, slabs)
         np.testing.assert_allclose(got_av, ref_av, rtol=AV_RTOL)
+
+
+@pytest.mark.parametrize("fuse", ["0", "1"])
+def test_graph_replay_is_bit_exact(lbm, oracle, monkeypatch, fuse):
+    """LBM_GRAPH=1: chunks of 64 timesteps + their reduce replayed as one hipGraph each (single slab);
+    several lbm_run calls with lengths around the chunk size, odd totals, both lattice parities."""
+    monkeypatch.setenv("LBM_GRAPH", "1")
+    monkeypatch.setenv("LBM_FUSE2", fuse)
+    p, ob, cells = random_case(lbm, 192, 40, 77)
+    calls = [130, 1, 64, 65, 7, 129, 4]           # 400 steps
+    ref = cells.copy()
+    ref_av = oracle.run(p, ref, ob, sum(calls))
+    with lbm.Engine(p, ob, cells) as eng:
+        for n in calls:
+            eng.run(n)
+        got = eng.cells()
+        got_av = eng.av_vels(sum(calls))
+    assert np.array_equal(ref.view(np.uint32), got.view(np.uint32))
+    np.testing.assert_allclose(got_av, ref_av, rtol=AV_RTOL)
