@@ -99,6 +99,8 @@ struct Slab {
 };
 
 constexpr int kSumBlocks = 1024;
+constexpr int kTileW = 16, kTileH = 8;  // step_tile: own cells per workgroup; one thread per staged cell
+constexpr int kTileStepsMax = 8;       // deepest instantiation (halo of 8 cells: 32 x 24 staged, 768 threads)
 constexpr int kHaloRows = 2;  // halo rows kept below and above every slab (two-step kernel needs 2)
 
 // One host thread per slab for the issue loop of a one-process multi-GPU run: a pass enqueues
@@ -202,6 +204,7 @@ struct lbm_ctx {
   int lane_cells = 4;               // cells per lane in step2_stream (4 or 2; LBM_LANE_CELLS)
   SlabTeam* team = nullptr;         // one issuing thread per slab (one-process multi-GPU), or null
   int use_graph = 0;                // single slab: replay kPartSlots timesteps + reduce as one hipGraph
+  int tile_steps = 0;               // > 0: single slab advanced by the LDS-tile kernel, this many steps per launch
 };
 
 namespace {
@@ -306,6 +309,41 @@ int launch_step2(lbm_ctx* c, int s, hipStream_t stream, int row_first, int row_e
   const fn kernel = table[c->math_mode == LBM_MATH_EXACT ? 0 : 1][c->nts][c->lane_cells == 2 ? 1 : 0];
   if (done) hipExtLaunchKernelGGL(kernel, dim3(waves), dim3(64), 0, stream, nullptr, done, 0, a);
   else hipLaunchKernelGGL(kernel, dim3(waves), dim3(64), 0, stream, a);
+  HIP_TRY(LBM_FAILURE, hipGetLastError());
+  return LBM_SUCCESS;
+}
+
+int tile_count(const lbm_ctx* c) { return ceil_div(c->p.nx, kTileW) * ceil_div(c->slab[0].rows, kTileH); }
+
+// n_steps <= c->tile_steps timesteps of the whole (single, periodic) slab from LDS tiles; partials of step j go
+// to slot slot_fill + j
+int launch_tile(lbm_ctx* c, hipStream_t stream, int n_steps, bool accel_after) {
+  Slab& sl = c->slab[0];
+  lbm::TileArgs a;
+  a.src = sl.lat[c->cur];
+  a.dst = sl.lat[c->cur ^ 1];
+  a.mask = sl.mask;
+  a.plane_stride = c->plane_stride;
+  a.row_pitch = c->row_pitch;
+  a.pitch = c->pitch;
+  a.nx = c->p.nx;
+  a.ny = sl.rows;
+  a.tiles_x = ceil_div(c->p.nx, kTileW);
+  a.n_steps = n_steps;
+  a.accel_row = sl.accel_row;
+  a.accel_after = accel_after ? 1 : 0;
+  a.omega = c->p.omega;
+  a.a1 = c->p.density * c->p.accel / 9.f;
+  a.a2 = c->p.density * c->p.accel / 36.f;
+  a.partials = sl.partials + (long)c->slot_fill * c->part_stride;
+  a.slot_stride = c->part_stride;
+  // halo depth 4 (24 x 16 staged cells) or 8 (32 x 24), one thread per staged cell
+  typedef void (*fn)(const lbm::TileArgs);
+  const bool exact = (c->math_mode == LBM_MATH_EXACT);
+  const bool deep = (c->tile_steps > 4);
+  const fn kernel = deep ? (exact ? (fn)lbm::step_tile<0, kTileW, kTileH, 8, 768> : (fn)lbm::step_tile<1, kTileW, kTileH, 8, 768>)
+                         : (exact ? (fn)lbm::step_tile<0, kTileW, kTileH, 4, 384> : (fn)lbm::step_tile<1, kTileW, kTileH, 4, 384>);
+  hipLaunchKernelGGL(kernel, dim3(tile_count(c)), dim3(deep ? 768 : 384), 0, stream, a);
   HIP_TRY(LBM_FAILURE, hipGetLastError());
   return LBM_SUCCESS;
 }
@@ -438,11 +476,18 @@ int capture_chunk(lbm_ctx* c, hipGraphExec_t* out) {
   int rc = LBM_SUCCESS;
   c->slot_fill = 0;
   for (int t = 0; t < kPartSlots && rc == LBM_SUCCESS;) {
-    const int adv = c->fuse2 ? 2 : 1;
-    rc = c->fuse2 ? launch_step2(c, 0, sl.compute, 0, sl.rows, c->band_rows, c->band_rows,
-                                 ceil_div(sl.rows, c->band_rows), 0, true)
-                  : launch_step(c, 0, sl.compute, 0, 1, sl.rows, 0, true);
-    const int n_part = c->fuse2 ? c->n_strips * ceil_div(sl.rows, c->band_rows) : sl.blocks_main;
+    const int adv = c->tile_steps ? c->tile_steps : (c->fuse2 ? 2 : 1);
+    int n_part;
+    if (c->tile_steps) {
+      rc = launch_tile(c, sl.compute, adv, true);
+      n_part = tile_count(c);
+    } else if (c->fuse2) {
+      rc = launch_step2(c, 0, sl.compute, 0, sl.rows, c->band_rows, c->band_rows, ceil_div(sl.rows, c->band_rows), 0, true);
+      n_part = c->n_strips * ceil_div(sl.rows, c->band_rows);
+    } else {
+      rc = launch_step(c, 0, sl.compute, 0, 1, sl.rows, 0, true);
+      n_part = sl.blocks_main;
+    }
     for (int k = 0; k < adv; k++) sl.slot_counts.n[c->slot_fill + k] = n_part;
     c->cur ^= 1;
     c->slot_fill += adv;
@@ -574,8 +619,9 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
   }
   int m = 0;  // macro step counter (event parity)
   for (int t = t_first; t < n_steps; m++) {
-    const bool two = c->fuse2 && (t + 1 < n_steps);
-    const int adv = two ? 2 : 1;
+    const int tile = (!halo && c->tile_steps) ? (c->tile_steps < n_steps - t ? c->tile_steps : n_steps - t) : 0;
+    const bool two = !tile && c->fuse2 && (t + 1 < n_steps);
+    const int adv = tile ? tile : (two ? 2 : 1);
     const bool last = (t + adv == n_steps);
     // phase 1: rows that touch no halo row (or the whole slab) on the compute streams
     if (for_slabs(c, [&](int s) -> int {
@@ -584,7 +630,9 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
           if (halo && m > 0) HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, sl.ev_boundary, 0));  // B(m-1)
           static const int ext_events = env_int("LBM_EXT_EVENTS", 1);
           hipEvent_t done = (halo && ext_events) ? sl.ev_interior[m & 1] : nullptr;  // I(m) done
-          if (two) {
+          if (tile) {
+            if (launch_tile(c, sl.compute, tile, !last) != LBM_SUCCESS) return LBM_FAILURE;
+          } else if (two) {
             const int r0 = halo ? 2 : 0, r1 = halo ? sl.rows - 2 : sl.rows;
             if (launch_step2(c, s, sl.compute, r0, r1, c->band_rows, c->band_rows, ceil_div(r1 - r0, c->band_rows), 0,
                              !last, done) != LBM_SUCCESS)
@@ -627,7 +675,8 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
       Slab& sl = c->slab[s];
       const int fused_waves = halo ? c->n_strips * (ceil_div(sl.rows - 4, c->band_rows) + 2)
                                    : c->n_strips * ceil_div(sl.rows, c->band_rows);
-      const int n_part = two ? fused_waves : sl.blocks_main + sl.blocks_boundary;
+      const int n_part = tile ? tile_count(c)
+                              : (two ? fused_waves : sl.blocks_main + sl.blocks_boundary);
       for (int k = 0; k < adv; k++) sl.slot_counts.n[c->slot_fill + k] = n_part;
     }
     c->cur ^= 1;
@@ -635,7 +684,7 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
     t += adv;
     // phase 3: the next exchange
     if (halo && !last && exchange_halos(c, depth, c->cur, c->cur, -1) != LBM_SUCCESS) return LBM_FAILURE;
-    if (c->slot_fill >= kPartSlots - 1 || last) {
+    if (c->slot_fill + (c->tile_steps > 2 ? c->tile_steps : 2) > kPartSlots || last) {
       if (flush_partials(c, flushed_upto) != LBM_SUCCESS) return LBM_FAILURE;
       flushed_upto += c->slot_fill;
       c->slot_fill = 0;
@@ -1009,6 +1058,20 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
     if (c->fuse2 && waves > max_blocks) max_blocks = waves;
   }
   if (world > 1 && params->ny / world < 4) c->fuse2 = 0;
+  // LDS-tile kernel (several timesteps per launch) for small single-slab grids: LBM_TILE_STEPS overrides
+  if (!halo_on) {
+    // measured (us per step, tile kernel at 4 steps per launch vs the one-step kernels): 128^2 2.09 vs 3.14,
+    // 256^2 2.88 vs 3.84, 384^2 4.29 vs 5.55, 512^2 6.12 vs 6.47, 640^2 8.42 vs 9.39, 1024^2 18.9 vs 13.4
+    // (asking for one of the other kernels by LBM_FUSE2 / LBM_VEC4 takes the tile kernel out of the default)
+    const bool other_kernel_requested = getenv("LBM_FUSE2") || getenv("LBM_VEC4");
+    c->tile_steps = env_int("LBM_TILE_STEPS",
+                            (!other_kernel_requested && (long)params->nx * params->ny <= 400L * 1024) ? 4 : 0);
+    if (c->tile_steps < 0 || c->tile_steps > kTileStepsMax) c->tile_steps = kTileStepsMax;
+    const int tiles = ceil_div(params->nx, kTileW) * ceil_div(params->ny, kTileH);
+    if (c->tile_steps && tiles > max_blocks) max_blocks = tiles;
+    // a graph chunk is kPartSlots timesteps in an even number of passes
+    if (c->tile_steps && (kPartSlots % c->tile_steps != 0 || (kPartSlots / c->tile_steps) % 2 != 0)) c->use_graph = 0;
+  }
   c->part_stride = round_up(max_blocks, 64);
 
   for (int s = 0; s < n_slabs; s++)
@@ -1129,7 +1192,7 @@ int lbm_get_info(const lbm_ctx* c, lbm_info* out) {
   out->world_rank = c->rank;
   out->world_size = c->world;
   const bool stale = (c->halo != HALO_SELF && c->halo_mode == LBM_HALO_STALE);
-  out->steps_per_launch = (c->fuse2 && !stale) ? 2 : 1;
+  out->steps_per_launch = (c->tile_steps && c->halo == HALO_SELF) ? c->tile_steps : ((c->fuse2 && !stale) ? 2 : 1);
   out->halo_mode = c->halo_mode;
   return LBM_SUCCESS;
 }

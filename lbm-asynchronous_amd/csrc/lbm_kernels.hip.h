@@ -675,6 +675,117 @@ __global__ __launch_bounds__(64) void step2_stream(const Step2Args a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Up to KMAX timesteps per launch from an LDS tile (temporal blocking for small, cache-resident grids,
+// single periodic slab).
+//
+// A grid of a few hundred thousand cells is not bound by bandwidth or arithmetic but by the latency of
+// one kernel (~3 us): every launch pays it, so the only lever is more timesteps per launch.  A workgroup
+// stages its TW x TH tile plus a halo of KMAX cells on every side -- all 9 populations and the obstacle
+// flags -- in LDS, and relaxes it n <= KMAX times in place: step j covers the cells at distance >= j from
+// the staged border (their 9 sources are cells of step j-1 inside the region), each thread pulls its
+// cells' populations from LDS into registers, the workgroup synchronises, the results go back to LDS.
+// After n steps the tile's own cells are exact and are stored; the halo cells were relaxed redundantly,
+// exactly as the neighbouring workgroups relax them (same per-cell code as every other kernel, so the
+// lattice stays bit-identical).  Periodic wrap in x and y is resolved when the tile is staged.
+// Sum of |u| per step: over the tile's own cells, one partial per workgroup and step.
+// ---------------------------------------------------------------------------------------------
+struct TileArgs {
+  const float* src;
+  float* dst;
+  const unsigned char* mask;
+  long plane_stride;
+  long row_pitch;
+  int pitch;
+  int nx, ny;
+  int tiles_x;      // workgroups across x
+  int n_steps;      // timesteps this launch advances (1..KMAX)
+  int accel_row;    // global row that receives accelerate_flow (ny - 2)
+  int accel_after;  // also apply the acceleration of the step after this launch's last one
+  float omega, a1, a2;
+  float* partials;  // partials[j * slot_stride + workgroup] = sum |u| of the tile's own cells after step j
+  long slot_stride;
+};
+
+template <int MATH, int TW, int TH, int KMAX, int THREADS = kBlock>
+__global__ __launch_bounds__(THREADS) void step_tile(const TileArgs a) {
+  constexpr int EW = TW + 2 * KMAX, EH = TH + 2 * KMAX, EC = EW * EH;
+  constexpr int EWP = EW + 1;                                           // row padding against bank conflicts
+  constexpr int MAXC = ((EW - 2) * (EH - 2) + THREADS - 1) / THREADS;   // cells per thread in step 1
+  __shared__ float f[kQ][EH][EWP];
+  __shared__ unsigned char blocked[EH][EW];
+  __shared__ int global_row[EH];
+
+  const int tid = threadIdx.x;
+  const int bx = blockIdx.x % a.tiles_x, by = blockIdx.x / a.tiles_x;
+  const int gx0 = bx * TW - KMAX, gy0 = by * TH - KMAX;
+  const long ps = a.plane_stride;
+
+  // stage the tile and its halo (periodic images where the halo leaves the grid)
+  for (int idx = tid; idx < EC; idx += THREADS) {
+    const int y = idx / EW, x = idx - y * EW;
+    int gy = (gy0 + y) % a.ny;  if (gy < 0) gy += a.ny;
+    int gx = (gx0 + x) % a.nx;  if (gx < 0) gx += a.nx;
+    const float* cell = a.src + (long)gy * a.row_pitch + gx;
+#pragma unroll
+    for (int k = 0; k < kQ; k++) f[k][y][x] = cell[k * ps];
+    blocked[y][x] = a.mask[(long)gy * a.pitch + gx];
+    if (x == 0) global_row[y] = gy;
+  }
+  __syncthreads();
+
+  for (int j = 1; j <= a.n_steps; j++) {
+    const int w = EW - 2 * j, n = w * (EH - 2 * j);
+    const bool accel = (j < a.n_steps) || a.accel_after;
+    float r[MAXC][kQ];
+    float my_sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+      const int idx = tid + c * THREADS;
+      if (idx < n) {
+        const int ry = idx / w;
+        const int y = j + ry, x = j + (idx - ry * w);
+        // pull (SerialCode/d2q9-bgk.c:263-271): speed k arrives from the cell it left one step ago
+        const float t[kQ] = {f[0][y][x],         f[1][y][x - 1],     f[2][y - 1][x],
+                             f[3][y][x + 1],     f[4][y + 1][x],     f[5][y - 1][x - 1],
+                             f[6][y - 1][x + 1], f[7][y + 1][x + 1], f[8][y + 1][x - 1]};
+        const int oy = y - KMAX, ox = x - KMAX;  // position inside the tile's own cells
+        const bool own = (oy >= 0) && (oy < TH) && (ox >= 0) && (ox < TW) && (by * TH + oy < a.ny) &&
+                         (bx * TW + ox < a.nx);
+        const bool lid = accel && (global_row[y] == a.accel_row);
+        float speed;
+        relax_cell<MATH>(t, blocked[y][x] != 0, lid, a.omega, a.a1, a.a2, r[c], speed, own);
+        if (own) my_sum += speed;
+      }
+    }
+    __syncthreads();  // every source of this step has been read
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+      const int idx = tid + c * THREADS;
+      if (idx < n) {
+        const int ry = idx / w;
+        const int y = j + ry, x = j + (idx - ry * w);
+#pragma unroll
+        for (int k = 0; k < kQ; k++) f[k][y][x] = r[c][k];
+      }
+    }
+    const float total = block_sum<THREADS>(my_sum);  // synchronises the workgroup
+    if (tid == 0) a.partials[(long)(j - 1) * a.slot_stride + blockIdx.x] = total;
+    __syncthreads();
+  }
+
+  // the tile's own cells
+  for (int idx = tid; idx < TW * TH; idx += THREADS) {
+    const int oy = idx / TW, ox = idx - oy * TW;
+    const int gy = by * TH + oy, gx = bx * TW + ox;
+    if (gy < a.ny && gx < a.nx) {
+      float* cell = a.dst + (long)gy * a.row_pitch + gx;
+#pragma unroll
+      for (int k = 0; k < kQ; k++) cell[k * ps] = f[k][oy + KMAX][ox + KMAX];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // fused step, 1 cell per lane: any nx (fallback for widths that are not a multiple of 4)
 // ---------------------------------------------------------------------------------------------
 template <bool EXACT>
