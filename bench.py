@@ -183,7 +183,33 @@ def main():
         return lbm.Engine(p, ob, None, math=args.math, rank=rank, world_size=world,
                           unique_id=uid[0], device=local_rank)
 
-    def measure(gx, gy, steps, warmup):
+    check = {}
+
+    def verify_against_single_gpu(p, ob, eng, av, total):
+        """After the timed region of a multi-rank run: every rank re-runs the SAME workload as one
+        periodic slab on its own GPU and compares its rows of the final u_x, u_y, |u| and pressure
+        fields bit for bit, and the all-reduced av_vels (which differ by summation order only)."""
+        info = eng.info()
+        mine = eng.final_state()
+        forced = os.environ.pop("LBM_FORCE_HALO", None)     # the reference run is a plain periodic slab
+        try:
+            with lbm.Engine(p, ob, None, math=args.math, rank=0, world_size=1,
+                            unique_id=lbm.rccl_unique_id(), device=local_rank) as ref:
+                ref.run(total)
+                ref_av = ref.av_vels(total)
+                whole = ref.final_state()
+        finally:
+            if forced is not None:
+                os.environ["LBM_FORCE_HALO"] = forced
+        rows = slice(info["row_first"], info["row_first"] + info["row_count"])
+        same = all(np.array_equal(mine[k].view(np.uint32), whole[k][rows].view(np.uint32)) for k in mine)
+        rel = float(np.max(np.abs(av.astype(np.float64) - ref_av) / np.abs(ref_av)))
+        t = torch.tensor([0.0 if same else 1.0, rel], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        check.update({"fields_bitwise_equal_to_single_gpu_run": bool(t[0] == 0.0),
+                      "av_vels_max_rel_diff": float(t[1]), "ranks_checked": world, "steps": total})
+
+    def measure(gx, gy, steps, warmup, verify=False):
         """One timed run of `steps` timesteps of a gx x gy grid after `warmup` untimed ones: barrier +
         device sync on both sides, max over ranks.  Returns (seconds, kernel ms per step,
         steps_per_launch, av_vels finite, workload description)."""
@@ -211,10 +237,18 @@ def main():
         av = eng.av_vels(warmup + steps)          # forces the cross-rank reduce too
         finite = bool(np.isfinite(av).all())
         spl = eng.info()["steps_per_launch"]
+        if verify:
+            try:
+                verify_against_single_gpu(p, ob, eng, av, warmup + steps)
+            except Exception as exc:
+                check["error"] = str(exc)
         eng.close()
         return elapsed, kernel_ms, spl, finite, workload
 
-    elapsed, kernel_ms, steps_per_launch, finite, workload = measure(nx, ny, args.steps, args.warmup)
+    # (outside the timed region) a multi-rank result is checked against a single-GPU run of the same workload
+    verify = use_rank_api and (world > 1 or os.environ.get("LBM_FORCE_HALO") == "1") and \
+        os.environ.get("LBM_BENCH_VERIFY", "1") != "0"
+    elapsed, kernel_ms, steps_per_launch, finite, workload = measure(nx, ny, args.steps, args.warmup, verify)
 
     # BASELINE.json's other named configurations, measured the same way (every rank takes part):
     # the reference's own 1024x1024 data set (20 000 steps in the reference; Infinity-Cache resident,
@@ -273,6 +307,8 @@ def main():
                          else "achieved = algorithmic bytes (72 B per lattice update) / launch time"},
             "results_finite": finite,
         }
+        if check:
+            line["multi_gpu_check"] = check
         if also:
             line["also"] = also
         if world == 1 and not args.no_cpu_baseline:
