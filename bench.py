@@ -256,8 +256,12 @@ def main():
     # reported as measured) and the 16384x16384 synthetic grid of the scaling configuration
     also = {}
     if os.environ.get("LBM_BENCH_ALSO", "1") != "0":
-        for (gx, gy, st, wu, note) in ((1024, 1024, 2000, 200, "reference data set 1024x1024, cache resident"),
-                                       (16384, 16384, 100, 10, "synthetic 16384x16384 (BASELINE.json configs[4])")):
+        extra = [(1024, 1024, 2000, 200, "reference data set 1024x1024, cache resident"),
+                 (16384, 16384, 100, 10, "synthetic 16384x16384 (BASELINE.json configs[4])")]
+        if world > 1:
+            # the same per-GPU work as the 1-GPU line (weak scaling): 8192 x 8192 cells per rank
+            extra.append((8192, 8192 * world, 100, 10, f"weak scaling: 8192x8192 cells per GPU, {world} GPUs"))
+        for (gx, gy, st, wu, note) in extra:
             if (gx, gy) == (nx, ny):
                 continue
             try:
