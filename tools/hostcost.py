@@ -1,3 +1,6 @@
+"""Host issue cost vs wall time per timestep of the halo pipelines on a tiny grid (256x256), where the
+device work is negligible: python tools/hostcost.py self|memcpy1|rccl1|memcpy2|memcpy4|rank1
+(set LBM_FORCE_HALO=1 for the single-slab halo variants)."""
 import sys,time,os; sys.path.insert(0,"tests"); import conftest; lbm=conftest.load_package()
 p,ob=conftest.dataset("256x256")
 p.max_iters=30000
