@@ -998,8 +998,8 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
     }
     if (sl.blocks_main + sl.blocks_boundary > max_blocks) max_blocks = sl.blocks_main + sl.blocks_boundary;
   }
-  // two-steps-per-pass geometry (single periodic slab only)
   // ---- which kernel, and its geometry (all measured on MI355X; profiles/r01_tuning.md) --------
+  //   single periodic slab up to 400 Ki cells: LDS tiles, 4 timesteps per launch (step_tile; set further down)
   //   slab < 1.5 Mi cells: single periodic slab: one timestep per pass (step_vec4); the grid is cache
   //                        resident and one resident wave of workgroups covers it (1024^2: 13.5 us vs
   //                        13.8+ two-step).  With halos: two timesteps per pass (half the exchanges).
