@@ -99,8 +99,19 @@ struct Slab {
 };
 
 constexpr int kSumBlocks = 1024;
-constexpr int kTileW = 16, kTileH = 8;  // step_tile: own cells per workgroup; one thread per staged cell
-constexpr int kTileStepsMax = 8;       // deepest instantiation (halo of 8 cells: 32 x 24 staged, 768 threads)
+// step_tile instantiations: own cells per workgroup (tw x th), halo depth = most timesteps per launch, threads
+struct TileShape { int tw, th, kmax, threads; void (*exact)(const lbm::TileArgs); void (*fast)(const lbm::TileArgs); };
+#define LBM_TILE_SHAPE(TW, TH, K, T) {TW, TH, K, T, lbm::step_tile<0, TW, TH, K, T>, lbm::step_tile<1, TW, TH, K, T>}
+const TileShape kTileShapes[] = {
+    LBM_TILE_SHAPE(16, 8, 4, 384),   // 0: tiny grids: one thread per staged cell (24 x 16)
+    LBM_TILE_SHAPE(16, 8, 8, 768),   // 1: same, halo of 8
+    LBM_TILE_SHAPE(32, 16, 2, 640),  // 2..: larger tiles, less redundant halo work
+    LBM_TILE_SHAPE(32, 16, 3, 768),
+    LBM_TILE_SHAPE(32, 16, 4, 896),
+    LBM_TILE_SHAPE(64, 16, 2, 640),
+    LBM_TILE_SHAPE(64, 8, 2, 704),
+};
+constexpr int kTileShapeCount = (int)(sizeof(kTileShapes) / sizeof(kTileShapes[0]));
 constexpr int kHaloRows = 2;  // halo rows kept below and above every slab (two-step kernel needs 2)
 
 // One host thread per slab for the issue loop of a one-process multi-GPU run: a pass enqueues
@@ -205,6 +216,7 @@ struct lbm_ctx {
   SlabTeam* team = nullptr;         // one issuing thread per slab (one-process multi-GPU), or null
   int use_graph = 0;                // single slab: replay kPartSlots timesteps + reduce as one hipGraph
   int tile_steps = 0;               // > 0: single slab advanced by the LDS-tile kernel, this many steps per launch
+  int tile_shape = 0;               // index into kTileShapes
 };
 
 namespace {
@@ -313,7 +325,13 @@ int launch_step2(lbm_ctx* c, int s, hipStream_t stream, int row_first, int row_e
   return LBM_SUCCESS;
 }
 
-int tile_count(const lbm_ctx* c) { return ceil_div(c->p.nx, kTileW) * ceil_div(c->slab[0].rows, kTileH); }
+int tile_count_for(const lbm_params* p, int shape) {
+  return ceil_div(p->nx, kTileShapes[shape].tw) * ceil_div(p->ny, kTileShapes[shape].th);
+}
+int tile_count(const lbm_ctx* c) {
+  const TileShape& t = kTileShapes[c->tile_shape];
+  return ceil_div(c->p.nx, t.tw) * ceil_div(c->slab[0].rows, t.th);
+}
 
 // n_steps <= c->tile_steps timesteps of the whole (single, periodic) slab from LDS tiles; partials of step j go
 // to slot slot_fill + j
@@ -328,7 +346,6 @@ int launch_tile(lbm_ctx* c, hipStream_t stream, int n_steps, bool accel_after) {
   a.pitch = c->pitch;
   a.nx = c->p.nx;
   a.ny = sl.rows;
-  a.tiles_x = ceil_div(c->p.nx, kTileW);
   a.n_steps = n_steps;
   a.accel_row = sl.accel_row;
   a.accel_after = accel_after ? 1 : 0;
@@ -337,13 +354,9 @@ int launch_tile(lbm_ctx* c, hipStream_t stream, int n_steps, bool accel_after) {
   a.a2 = c->p.density * c->p.accel / 36.f;
   a.partials = sl.partials + (long)c->slot_fill * c->part_stride;
   a.slot_stride = c->part_stride;
-  // halo depth 4 (24 x 16 staged cells) or 8 (32 x 24), one thread per staged cell
-  typedef void (*fn)(const lbm::TileArgs);
-  const bool exact = (c->math_mode == LBM_MATH_EXACT);
-  const bool deep = (c->tile_steps > 4);
-  const fn kernel = deep ? (exact ? (fn)lbm::step_tile<0, kTileW, kTileH, 8, 768> : (fn)lbm::step_tile<1, kTileW, kTileH, 8, 768>)
-                         : (exact ? (fn)lbm::step_tile<0, kTileW, kTileH, 4, 384> : (fn)lbm::step_tile<1, kTileW, kTileH, 4, 384>);
-  hipLaunchKernelGGL(kernel, dim3(tile_count(c)), dim3(deep ? 768 : 384), 0, stream, a);
+  const TileShape& t = kTileShapes[c->tile_shape];
+  a.tiles_x = ceil_div(c->p.nx, t.tw);
+  hipLaunchKernelGGL(c->math_mode == LBM_MATH_EXACT ? t.exact : t.fast, dim3(tile_count(c)), dim3(t.threads), 0, stream, a);
   HIP_TRY(LBM_FAILURE, hipGetLastError());
   return LBM_SUCCESS;
 }
@@ -1060,15 +1073,20 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
   if (world > 1 && params->ny / world < 4) c->fuse2 = 0;
   // LDS-tile kernel (several timesteps per launch) for small single-slab grids: LBM_TILE_STEPS overrides
   if (!halo_on) {
-    // measured (us per step, tile kernel at 4 steps per launch vs the one-step kernels): 128^2 2.09 vs 3.14,
-    // 256^2 2.88 vs 3.84, 384^2 4.29 vs 5.55, 512^2 6.12 vs 6.47, 640^2 8.42 vs 9.39, 1024^2 18.9 vs 13.4
+    // measured (us per step; one-step kernels | 16x8 tiles, 4 steps per launch | 32x16 tiles, 3 steps per launch):
+    //   128^2 3.14 | 2.09 | -      256^2 3.84 | 2.82 | 3.54    384^2 5.65 | 4.19 | 5.43    448^2 6.14 | 5.44 | 5.26
+    //   512^2 6.56 | 6.02 | 5.34   640^2 9.38 | 8.34 | 8.89    768^2 11.28 | 11.22 | 10.14  896^2 12.70 | 14.7 | 13.8
+    //   1024^2 13.34 | 18.8 | 15.1 -- from there the redundant halo work costs more than the launches it saves
     // (asking for one of the other kernels by LBM_FUSE2 / LBM_VEC4 takes the tile kernel out of the default)
     const bool other_kernel_requested = getenv("LBM_FUSE2") || getenv("LBM_VEC4");
-    c->tile_steps = env_int("LBM_TILE_STEPS",
-                            (!other_kernel_requested && (long)params->nx * params->ny <= 400L * 1024) ? 4 : 0);
-    if (c->tile_steps < 0 || c->tile_steps > kTileStepsMax) c->tile_steps = kTileStepsMax;
-    const int tiles = ceil_div(params->nx, kTileW) * ceil_div(params->ny, kTileH);
-    if (c->tile_steps && tiles > max_blocks) max_blocks = tiles;
+    const long cells = (long)params->nx * params->ny;
+    const int dflt_shape = (cells <= 200L * 1024) ? 0 : 3;
+    const int dflt_steps = (other_kernel_requested || cells > 600L * 1024) ? 0 : kTileShapes[dflt_shape].kmax;
+    c->tile_steps = env_int("LBM_TILE_STEPS", dflt_steps);
+    c->tile_shape = env_int("LBM_TILE_SHAPE", getenv("LBM_TILE_STEPS") ? (c->tile_steps > 4 ? 1 : 0) : dflt_shape);
+    if (c->tile_shape < 0 || c->tile_shape >= kTileShapeCount) c->tile_shape = 0;
+    if (c->tile_steps < 0 || c->tile_steps > kTileShapes[c->tile_shape].kmax) c->tile_steps = kTileShapes[c->tile_shape].kmax;
+    if (c->tile_steps && tile_count_for(params, c->tile_shape) > max_blocks) max_blocks = tile_count_for(params, c->tile_shape);
     // a graph chunk is kPartSlots timesteps in an even number of passes
     if (c->tile_steps && (kPartSlots % c->tile_steps != 0 || (kPartSlots / c->tile_steps) % 2 != 0)) c->use_graph = 0;
   }

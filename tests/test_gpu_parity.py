@@ -411,6 +411,8 @@ def test_lds_tile_kernel_bitwise(lbm, oracle, monkeypatch, nx, ny, tile_steps):
     Ragged tile edges, step counts that are not multiples of the launch depth, run in pieces, graph
     replay on and off: lattice bit-identical to the oracle."""
     monkeypatch.setenv("LBM_TILE_STEPS", tile_steps)
+    if tile_steps == "3":
+        monkeypatch.setenv("LBM_TILE_SHAPE", "3")              # 32x16 own cells, halo of 3 (mid-size default)
     p, ob, cells = random_case(lbm, nx, ny, nx + ny)
     for graph in ("0", "1"):
         monkeypatch.setenv("LBM_GRAPH", graph)
@@ -428,3 +430,23 @@ def test_lds_tile_kernel_bitwise(lbm, oracle, monkeypatch, nx, ny, tile_steps):
         np.testing.assert_allclose(got_av, ref_av, rtol=AV_RTOL)
         want = oracle.final_state(p, ref, ob)
         assert np.array_equal(fields["pressure"].view(np.uint32), want["pressure"].view(np.uint32))
+
+
+@pytest.mark.parametrize("shape,steps", [("2", "2"), ("4", "4"), ("5", "2"), ("6", "1")])
+def test_lds_tile_shapes_bitwise(lbm, oracle, monkeypatch, shape, steps):
+    """The other step_tile instantiations (LBM_TILE_SHAPE) on a grid whose edges cut through tiles."""
+    monkeypatch.setenv("LBM_TILE_SHAPE", shape)
+    monkeypatch.setenv("LBM_TILE_STEPS", steps)
+    p, ob, cells = random_case(lbm, 200, 51, 9)
+    ref_cells, ref_av, got_cells, got_av, _ = run_both(lbm, oracle, p, ob, cells, 37)
+    assert np.array_equal(ref_cells.view(np.uint32), got_cells.view(np.uint32))
+    np.testing.assert_allclose(got_av, ref_av, rtol=AV_RTOL)
+
+
+def test_default_kernel_by_grid_size(lbm, datasets):
+    """The policy of DESIGN.md section 6: LDS tiles up to 600 Ki cells, one step per pass up to 1.5 Mi, then two."""
+    for n, want in ((128, 4), (448, 4), (512, 3), (768, 3), (1024, 1), (1280, 2)):
+        p = lbm.Params(n, n, 4, 10, 0.1, 0.005, 1.85)
+        ob = np.zeros((n, n), dtype=np.int32)
+        with lbm.Engine(p, ob, None) as eng:
+            assert eng.info()["steps_per_launch"] == want, n
