@@ -1012,11 +1012,12 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
     if (sl.blocks_main + sl.blocks_boundary > max_blocks) max_blocks = sl.blocks_main + sl.blocks_boundary;
   }
   // ---- which kernel, and its geometry (all measured on MI355X; profiles/r01_tuning.md) --------
-  //   single periodic slab up to 400 Ki cells: LDS tiles, 4 timesteps per launch (step_tile; set further down)
-  //   slab < 1.5 Mi cells: single periodic slab: one timestep per pass (step_vec4); the grid is cache
-  //                        resident and one resident wave of workgroups covers it (1024^2: 13.5 us vs
-  //                        13.8+ two-step).  With halos: two timesteps per pass (half the exchanges).
-  //   1.5 .. 6 Mi cells  : two timesteps per pass, 2 cells per lane (93 VGPRs, 5 waves/SIMD: twice the
+  //   single periodic slab below 560 Ki cells: LDS tiles, 4 or 3 timesteps per launch (step_tile; set further
+  //                        down).  With halos: two timesteps per pass (half the exchanges).
+  //   (one timestep per pass, step_vec4 / step_scalar: the odd last step of a run, widths that are not a multiple
+  //                        of 4, LBM_FUSE2=0; it was the default up to 1.5 Mi cells until the two-step kernel stopped
+  //                        computing |u| on its warm-up rows: 768^2 9.8 vs 11.3 us, 1024^2 12.35 vs 13.23, 1152^2 15.3 vs 18.1)
+  //   0.56 .. 6 Mi cells : two timesteps per pass, 2 cells per lane (93 VGPRs, 5 waves/SIMD: twice the
   //                        waves of the 4-cell form; 1280^2: 19.1 vs 21.2 us, 2048^2: 40 vs 51.5 (one-step))
   //   >= 6 Mi cells      : two timesteps per pass, 4 cells per lane (16-byte accesses; 8192^2: 517 us vs
   //                        575 (2-cell) vs 802 (one-step))
@@ -1029,7 +1030,7 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
   // Across slabs / ranks a pass costs one exchange and ~10 runtime calls per slab whatever it computes, so
   // two timesteps per pass always pay there (1024^2 over 2/4/8 slabs on one device: 45/74/97 us per step
   // vs 70/113/125 one-step; 2048^2 over 8: 96 vs 261).
-  c->fuse2 = (c->vec4 && env_int("LBM_FUSE2", (min_cells >= 3L * 512 * 1024 || halo_on) ? 1 : 0)) ? 1 : 0;
+  c->fuse2 = (c->vec4 && env_int("LBM_FUSE2", (min_cells >= 560L * 1024 || halo_on) ? 1 : 0)) ? 1 : 0;
   c->lane_cells = env_int("LBM_LANE_CELLS", min_cells >= 6L * 1024 * 1024 ? 4 : 2) == 2 ? 2 : 4;
   c->n_strips = ceil_div(params->nx / c->lane_cells > 0 ? params->nx / c->lane_cells : 1, lbm::kStripQuads);
   // Band height.  A wave sweeps band_rows + 2 rows.  4-cell form: 256 CUs x 12 waves are resident
@@ -1081,7 +1082,7 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
     const bool other_kernel_requested = getenv("LBM_FUSE2") || getenv("LBM_VEC4");
     const long cells = (long)params->nx * params->ny;
     const int dflt_shape = (cells <= 200L * 1024) ? 0 : 3;
-    const int dflt_steps = (other_kernel_requested || cells > 600L * 1024) ? 0 : kTileShapes[dflt_shape].kmax;
+    const int dflt_steps = (other_kernel_requested || cells >= 560L * 1024) ? 0 : kTileShapes[dflt_shape].kmax;
     c->tile_steps = env_int("LBM_TILE_STEPS", dflt_steps);
     c->tile_shape = env_int("LBM_TILE_SHAPE", getenv("LBM_TILE_STEPS") ? (c->tile_steps > 4 ? 1 : 0) : dflt_shape);
     if (c->tile_shape < 0 || c->tile_shape >= kTileShapeCount) c->tile_shape = 0;
