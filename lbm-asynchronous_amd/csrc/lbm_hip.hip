@@ -1042,7 +1042,7 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
   {
     // many rounds of waves: measured optimum 6-7 rows up to 8192 cells per row (8192^2: 480 us vs
     // 515 at 8), 5 at 12288 (747 vs 811), 4 at 16384 and wider (16384^2: 1993 vs 2282 us at 8)
-    int pick = (params->nx <= 8192) ? 6 : (params->nx <= 12288 ? 5 : 4);
+    int pick = (params->nx <= 8192) ? 7 : (params->nx <= 12288 ? 5 : 4);  // 8192^2: 7 rows 0.477-0.480 ms, 6 rows 0.481-0.484
     const long resident = 256L * 4 * (c->lane_cells == 4 ? 3 : 5);  // waves resident at once
     const long slab_rows = (n_slabs > 1 || world > 1) ? (c->row_count / n_slabs) - 4 : c->row_count;
     const long rows_eff = slab_rows > 1 ? slab_rows : 1;
