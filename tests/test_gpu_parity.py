@@ -450,3 +450,19 @@ def test_default_kernel_by_grid_size(lbm, datasets):
         ob = np.zeros((n, n), dtype=np.int32)
         with lbm.Engine(p, ob, None) as eng:
             assert eng.info()["steps_per_launch"] == want, n
+
+
+@pytest.mark.parametrize("nx,ny", [(1, 2), (2, 2), (3, 3), (5, 2), (4, 2), (8, 3), (4, 5), (12, 4)])
+@pytest.mark.parametrize("kernel", ["default", "one-step", "two-step"])
+def test_degenerate_grid_sizes_bitwise(lbm, oracle, monkeypatch, nx, ny, kernel):
+    """The smallest grids the parameter check admits (ny >= 2, nx >= 1): every neighbour is a periodic
+    image of the cell itself or of the one other row; each kernel family must still follow the oracle."""
+    if kernel != "default":
+        monkeypatch.setenv("LBM_FUSE2", "1" if kernel == "two-step" else "0")
+    p, ob, cells = random_case(lbm, nx, ny, 100 + nx * ny, blocked_frac=0.0, walls=False)
+    ob[:] = 0
+    if nx * ny > 4:
+        ob[0, 0] = 1
+    ref_cells, ref_av, got_cells, got_av, _ = run_both(lbm, oracle, p, ob, cells, 9)
+    assert np.array_equal(ref_cells.view(np.uint32), got_cells.view(np.uint32))
+    np.testing.assert_allclose(got_av, ref_av, rtol=AV_RTOL)
