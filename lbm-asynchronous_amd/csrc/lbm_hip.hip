@@ -1033,25 +1033,21 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
   c->fuse2 = (c->vec4 && env_int("LBM_FUSE2", (min_cells >= 560L * 1024 || halo_on) ? 1 : 0)) ? 1 : 0;
   c->lane_cells = env_int("LBM_LANE_CELLS", min_cells >= 6L * 1024 * 1024 ? 4 : 2) == 2 ? 2 : 4;
   c->n_strips = ceil_div(params->nx / c->lane_cells > 0 ? params->nx / c->lane_cells : 1, lbm::kStripQuads);
-  // Band height.  A wave sweeps band_rows + 2 rows.  4-cell form: 256 CUs x 12 waves are resident
-  // at once; big slabs run many rounds of waves and like short bands (5-6 rows),
-  // a slab that fits in a few rounds is quantised by them -- pick the height that
-  // fills k rounds exactly (8192x1024: 12 rows = 0.95 rounds 76.7 us, 11 rows = 1.04 rounds
-  // 87.7 us).  The 2-cell form (mid-size grids) keeps 256 x 20 waves resident; same rule
-  // (1536^2: 4 rows = 0.98 rounds 24.0 us, 8 rows 25.3 us).
+  // Band height.  A wave sweeps band_rows + 2 rows.
+  //   4-cell form (256 CUs x 12 waves resident): short bands, by row width -- measured optimum 7 rows at 8192 cells
+  //   per row (8192^2: 0.477-0.480 ms vs 0.481-0.484 at 6, 0.495 at 4; same in the halo pipeline), 4-5 rows for
+  //   narrower and for wider rows (7168^2: 0.384 at 4 vs 0.411 at 7; 6144^2: 0.277 at 5 vs 0.303 at 7; 4096^2
+  //   0.131-0.132 at 4-7; 12288: 5; 16384^2: 2.01 at 4 vs 2.23 at 6).  Fitting whole rounds of resident waves
+  //   does NOT pay here (4096^2: 0.146 with the round model's 23-row bands vs 0.131; 8192x2048: 0.139 vs 0.126).
+  //   2-cell form (mid-size grids, 256 x 20 waves resident): a slab that fits in a few rounds is quantised by
+  //   them -- pick the height that fills k rounds exactly (1536^2: 4 rows = 0.98 rounds 24.0 us, 8 rows 25.3 us).
   {
-    // many rounds of waves: measured optimum 6-7 rows up to 8192 cells per row (8192^2: 480 us vs
-    // 515 at 8), 5 at 12288 (747 vs 811), 4 at 16384 and wider (16384^2: 1993 vs 2282 us at 8)
-    int pick = (params->nx <= 8192) ? 7 : (params->nx <= 12288 ? 5 : 4);  // 8192^2: 7 rows 0.477-0.480 ms, 6 rows 0.481-0.484
-    const long resident = 256L * 4 * (c->lane_cells == 4 ? 3 : 5);  // waves resident at once
+    int pick = (params->nx <= 7168) ? 5 : (params->nx <= 8192 ? 7 : (params->nx <= 12288 ? 5 : 4));
+    const long resident = 256L * 4 * 5;  // 2-cell waves resident at once
     const long slab_rows = (n_slabs > 1 || world > 1) ? (c->row_count / n_slabs) - 4 : c->row_count;
     const long rows_eff = slab_rows > 1 ? slab_rows : 1;
-    // (in the interior/boundary pipeline of a multi-slab run the 4-cell form keeps the short bands:
-    // one rank's share of 8192^2 through the rank pipeline, us per step at band 6-7 vs the round
-    // model's pick: 8192x2048 139 vs 149, 8192x1024 77-78 vs 79-82, 8192x4096 251-258 either way)
-    const bool round_model = !(halo_on && c->lane_cells == 4);
-    if (round_model && (long)c->n_strips * ceil_div(rows_eff, 8) < 5 * resident) {
-      const long lo = (c->lane_cells == 4) ? 4 : 3;
+    if (c->lane_cells == 2 && (long)c->n_strips * ceil_div(rows_eff, 8) < 5 * resident) {
+      const long lo = 3;
       long best_cost = -1;
       for (int k = 1; k <= 4; k++) {
         long b = (rows_eff * c->n_strips + k * resident - 1) / (k * resident);
