@@ -137,6 +137,16 @@ def pmc_traffic(nx, ny, steps_per_launch):
         return None
 
 
+def pmc_extra(nx, ny, steps_per_launch, what):
+    """Other committed PMC figures of the same kernel and grid (profiles/pmc_traffic.json), e.g. the fraction of
+    SIMD cycles in which a VALU instruction issues."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            return json.load(fh).get(f"{nx}x{ny}/steps_per_launch={steps_per_launch}/{what}")
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -305,11 +315,13 @@ def main():
                          "launch_ms": launch_ms, "kernel_ms_per_step": kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "traffic_GBps": (traffic / (launch_ms * 1e-3) / 1e9) if traffic else None,
+                         "valu_busy_pmc": pmc_extra(nx, ny, steps_per_launch, "valu_busy") if world == 1 else None,
                          "note": ("achieved = algorithmic bytes (72 B per lattice update) / launch time; "
                                   "the two-step kernel reads and writes the lattice once per TWO updates, "
                                   "so achieved may exceed the HBM peak while the bytes actually moved "
                                   "(traffic: rocprofv3 PMC at the L2-fabric boundary, Infinity-Cache hits "
-                                  "included) stay below the algorithmic count") if steps_per_launch == 2
+                                  "included) stay below the algorithmic count; at that point the kernel is bound by VALU issue "
+                                  "(valu_busy_pmc = share of SIMD cycles issuing a VALU instruction)") if steps_per_launch == 2
                          else "achieved = algorithmic bytes (72 B per lattice update) / launch time"},
             "results_finite": finite,
         }
