@@ -21,6 +21,7 @@ import os
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 
 import numpy as np
@@ -166,9 +167,12 @@ def main():
                          f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port 29500 "
                          f"bench.py --gpus {args.gpus} ...")
 
-    # RCCL prints a five-line version banner on stdout at communicator creation unless told not to;
-    # stdout must carry exactly one JSON line (errors are still reported at this level)
-    os.environ.setdefault("NCCL_DEBUG", "ERROR")
+    # stdout must carry exactly ONE JSON line, but RCCL prints a five-line version banner on the C-level stdout
+    # at communicator creation (whatever NCCL_DEBUG says): keep the real stdout aside for the line and point
+    # file descriptor 1 at stderr for everything else
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -196,97 +200,13 @@ def main():
                           unique_id=uid[0], device=local_rank)
 
     check = {}
-
-    def verify_against_single_gpu(p, ob, eng, av, total):
-        """After the timed region of a multi-rank run: every rank re-runs the SAME workload as one
-        periodic slab on its own GPU and compares its rows of the final u_x, u_y, |u| and pressure
-        fields bit for bit, and the all-reduced av_vels (which differ by summation order only)."""
-        info = eng.info()
-        mine = eng.final_state()
-        forced = os.environ.pop("LBM_FORCE_HALO", None)     # the reference run is a plain periodic slab
-        try:
-            with lbm.Engine(p, ob, None, math=args.math, rank=0, world_size=1,
-                            unique_id=lbm.rccl_unique_id(), device=local_rank) as ref:
-                ref.run(total)
-                ref_av = ref.av_vels(total)
-                whole = ref.final_state()
-        finally:
-            if forced is not None:
-                os.environ["LBM_FORCE_HALO"] = forced
-        rows = slice(info["row_first"], info["row_first"] + info["row_count"])
-        same = all(np.array_equal(mine[k].view(np.uint32), whole[k][rows].view(np.uint32)) for k in mine)
-        rel = float(np.max(np.abs(av.astype(np.float64) - ref_av) / np.abs(ref_av)))
-        t = torch.tensor([0.0 if same else 1.0, rel], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        check.update({"fields_bitwise_equal_to_single_gpu_run": bool(t[0] == 0.0),
-                      "av_vels_max_rel_diff": float(t[1]), "ranks_checked": world, "steps": total})
-
-    def measure(gx, gy, steps, warmup, verify=False):
-        """One timed run of `steps` timesteps of a gx x gy grid after `warmup` untimed ones: barrier +
-        device sync on both sides, max over ranks.  Returns (seconds, kernel ms per step,
-        steps_per_launch, av_vels finite, workload description)."""
-        p, ob, workload = synthetic_case(lbm, gx, gy, warmup + steps)
-        eng = make_engine(p, ob)
-
-        def fence():
-            eng.sync()
-            torch.cuda.synchronize()
-            if use_rank_api:
-                dist.barrier()
-                torch.cuda.synchronize()
-
-        if warmup > 0:
-            eng.run(warmup)
-        fence()
-        t0 = time.perf_counter()
-        kernel_ms = eng.run_timed(steps)
-        fence()
-        elapsed = time.perf_counter() - t0
-        if use_rank_api:
-            t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed, kernel_ms = float(t[0]), float(t[1])
-        av = eng.av_vels(warmup + steps)          # forces the cross-rank reduce too
-        finite = bool(np.isfinite(av).all())
-        spl = eng.info()["steps_per_launch"]
-        if verify:
-            try:
-                verify_against_single_gpu(p, ob, eng, av, warmup + steps)
-            except Exception as exc:
-                check["error"] = str(exc)
-        eng.close()
-        return elapsed, kernel_ms, spl, finite, workload
-
-    # (outside the timed region) a multi-rank result is checked against a single-GPU run of the same workload
-    verify = use_rank_api and (world > 1 or os.environ.get("LBM_FORCE_HALO") == "1") and \
-        os.environ.get("LBM_BENCH_VERIFY", "1") != "0"
-    elapsed, kernel_ms, steps_per_launch, finite, workload = measure(nx, ny, args.steps, args.warmup, verify)
-
-    # BASELINE.json's other named configurations, measured the same way (every rank takes part):
-    # the reference's own 1024x1024 data set (20 000 steps in the reference; Infinity-Cache resident,
-    # so MLUPS only, no HBM figure; strong-scaling it over several GPUs is exchange-latency bound and
-    # reported as measured) and the 16384x16384 synthetic grid of the scaling configuration
     also = {}
-    if os.environ.get("LBM_BENCH_ALSO", "1") != "0":
-        extra = [(1024, 1024, 2000, 200, "reference data set 1024x1024, cache resident"),
-                 (16384, 16384, 100, 10, "synthetic 16384x16384 (BASELINE.json configs[4])")]
-        if world > 1:
-            # the same per-GPU work as the 1-GPU line (weak scaling): 8192 x 8192 cells per rank
-            extra.append((8192, 8192 * world, 100, 10, f"weak scaling: 8192x8192 cells per GPU, {world} GPUs"))
-        for (gx, gy, st, wu, note) in extra:
-            if (gx, gy) == (nx, ny):
-                continue
-            try:
-                dt, k_ms, spl, fin, _ = measure(gx, gy, st, wu)
-                also[f"{gx}x{gy}"] = {"value": gx * gy * st / dt / 1e6, "unit": "MLUPS", "n_gpus": args.gpus,
-                                      "ms_per_step": dt / st * 1e3, "kernel_ms_per_step": k_ms, "steps": st,
-                                      "warmup": wu, "steps_per_launch": spl, "results_finite": fin, "note": note}
-            except Exception as exc:            # never lose the main line over an extra one
-                also[f"{gx}x{gy}"] = {"error": str(exc)}
-                if use_rank_api:
-                    break                       # ranks may have diverged: stop issuing collectives
+    main_result = {}
+    printed = threading.Event()
 
-    if rank == 0:
+    def compose_line(extras_note=None):
+        elapsed, kernel_ms, steps_per_launch, finite, workload = (main_result[k] for k in
+                                                                  ("elapsed", "kernel_ms", "spl", "finite", "workload"))
         cells = float(nx) * float(ny)
         mlups = cells * args.steps / elapsed / 1e6
         # per-launch algorithmic bytes: this rank's share of the grid (max over ranks = ceil)
@@ -298,7 +218,7 @@ def main():
         launch_ms = kernel_ms * steps_per_launch
         achieved = algo_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
         traffic = pmc_traffic(nx, ny, steps_per_launch) if world == 1 else None
-        kernel_name = "lbm::step2_stream" if steps_per_launch == 2 else "lbm::step_vec4"
+        kernel_name = {2: "lbm::step2_stream", 1: "lbm::step_vec4"}.get(steps_per_launch, "lbm::step_tile")
         line = {
             "metric": "MLUPS", "value": mlups, "unit": "MLUPS (million lattice updates/s)",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
@@ -326,9 +246,126 @@ def main():
             "results_finite": finite,
         }
         if check:
-            line["multi_gpu_check"] = check
+            line["multi_gpu_check"] = dict(check)
         if also:
-            line["also"] = also
+            line["also"] = dict(also)
+        if extras_note:
+            line["extras_note"] = extras_note
+        return line
+
+    def print_once(line):
+        if not printed.is_set():
+            printed.set()
+            os.write(real_stdout, (json.dumps(line) + "\n").encode())
+
+    def extras_watchdog():
+        """The headline measurement is done; the verification and the extra configurations that follow must not
+        be able to lose it.  If they have not finished in time, rank 0 prints the line with what it has and
+        every rank leaves (a blocked HIP / RCCL call cannot be interrupted from Python)."""
+        if rank == 0:
+            print_once(compose_line("verification / extra configurations did not finish within "
+                                    f"{extras_timeout:.0f} s and were abandoned"))
+        os._exit(0 if rank == 0 else 3)
+
+    extras_timeout = float(os.environ.get("LBM_BENCH_EXTRA_TIMEOUT", "300"))
+
+    def verify_against_single_gpu(p, ob, eng, av, total):
+        """After the timed region of a multi-rank run: every rank re-runs the SAME workload as one
+        periodic slab on its own GPU and compares its rows of the final u_x, u_y, |u| and pressure
+        fields bit for bit, and the all-reduced av_vels (which differ by summation order only)."""
+        info = eng.info()
+        mine = eng.final_state()
+        forced = os.environ.pop("LBM_FORCE_HALO", None)     # the reference run is a plain periodic slab
+        try:
+            with lbm.Engine(p, ob, None, math=args.math, rank=0, world_size=1,
+                            unique_id=lbm.rccl_unique_id(), device=local_rank) as ref:
+                ref.run(total)
+                ref_av = ref.av_vels(total)
+                whole = ref.final_state()
+        finally:
+            if forced is not None:
+                os.environ["LBM_FORCE_HALO"] = forced
+        rows = slice(info["row_first"], info["row_first"] + info["row_count"])
+        same = all(np.array_equal(mine[k].view(np.uint32), whole[k][rows].view(np.uint32)) for k in mine)
+        rel = float(np.max(np.abs(av.astype(np.float64) - ref_av) / np.abs(ref_av)))
+        t = torch.tensor([0.0 if same else 1.0, rel], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        check.update({"fields_bitwise_equal_to_single_gpu_run": bool(t[0] == 0.0),
+                      "av_vels_max_rel_diff": float(t[1]), "ranks_checked": world, "steps": total})
+
+    watchdog = threading.Timer(extras_timeout, extras_watchdog)
+    watchdog.daemon = True
+
+    def measure(gx, gy, steps, warmup, verify=False, headline=False):
+        """One timed run of `steps` timesteps of a gx x gy grid after `warmup` untimed ones: barrier +
+        device sync on both sides, max over ranks.  Returns (seconds, kernel ms per step,
+        steps_per_launch, av_vels finite, workload description)."""
+        p, ob, workload = synthetic_case(lbm, gx, gy, warmup + steps)
+        eng = make_engine(p, ob)
+
+        def fence():
+            eng.sync()
+            torch.cuda.synchronize()
+            if use_rank_api:
+                dist.barrier()
+                torch.cuda.synchronize()
+
+        if warmup > 0:
+            eng.run(warmup)
+        fence()
+        t0 = time.perf_counter()
+        kernel_ms = eng.run_timed(steps)
+        fence()
+        elapsed = time.perf_counter() - t0
+        if use_rank_api:
+            t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed, kernel_ms = float(t[0]), float(t[1])
+        av = eng.av_vels(warmup + steps)          # forces the cross-rank reduce too
+        finite = bool(np.isfinite(av).all())
+        spl = eng.info()["steps_per_launch"]
+        if headline:
+            main_result.update(elapsed=elapsed, kernel_ms=kernel_ms, spl=spl, finite=finite, workload=workload)
+            watchdog.start()
+        if verify:
+            try:
+                verify_against_single_gpu(p, ob, eng, av, warmup + steps)
+            except Exception as exc:
+                check["error"] = str(exc)
+        eng.close()
+        return elapsed, kernel_ms, spl, finite, workload
+
+    # (outside the timed region) a multi-rank result is checked against a single-GPU run of the same workload
+    verify = use_rank_api and (world > 1 or os.environ.get("LBM_FORCE_HALO") == "1") and \
+        os.environ.get("LBM_BENCH_VERIFY", "1") != "0"
+    measure(nx, ny, args.steps, args.warmup, verify, headline=True)
+
+    # BASELINE.json's other named configurations, measured the same way (every rank takes part):
+    # the reference's own 1024x1024 data set (20 000 steps in the reference; Infinity-Cache resident,
+    # so MLUPS only, no HBM figure; strong-scaling it over several GPUs is exchange-latency bound and
+    # reported as measured) and the 16384x16384 synthetic grid of the scaling configuration
+    if os.environ.get("LBM_BENCH_ALSO", "1") != "0":
+        extra = [(1024, 1024, 2000, 200, "reference data set 1024x1024, cache resident"),
+                 (16384, 16384, 100, 10, "synthetic 16384x16384 (BASELINE.json configs[4])")]
+        if world > 1:
+            # the same per-GPU work as the 1-GPU line (weak scaling): 8192 x 8192 cells per rank
+            extra.append((8192, 8192 * world, 100, 10, f"weak scaling: 8192x8192 cells per GPU, {world} GPUs"))
+        for (gx, gy, st, wu, note) in extra:
+            if (gx, gy) == (nx, ny):
+                continue
+            try:
+                dt, k_ms, spl, fin, _ = measure(gx, gy, st, wu)
+                also[f"{gx}x{gy}"] = {"value": gx * gy * st / dt / 1e6, "unit": "MLUPS", "n_gpus": args.gpus,
+                                      "ms_per_step": dt / st * 1e3, "kernel_ms_per_step": k_ms, "steps": st,
+                                      "warmup": wu, "steps_per_launch": spl, "results_finite": fin, "note": note}
+            except Exception as exc:            # never lose the main line over an extra one
+                also[f"{gx}x{gy}"] = {"error": str(exc)}
+                if use_rank_api:
+                    break                       # ranks may have diverged: stop issuing collectives
+
+    watchdog.cancel()
+    if rank == 0:
+        line = compose_line()
         if world == 1 and not args.no_cpu_baseline:
             base = cpu_baseline(nx, ny)
             if base:
@@ -336,7 +373,7 @@ def main():
             ref = cpu_reference()
             if ref:
                 line["cpu_reference_1024x1024"] = ref
-        print(json.dumps(line), flush=True)
+        print_once(line)
 
     if use_rank_api:
         dist.destroy_process_group()
