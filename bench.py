@@ -10,9 +10,19 @@ obstacle map is the reference's 1024x1024 map tiled 8x8, uniform-equilibrium sta
 For N > 1 (launched by torch.distributed.run, one rank per GPU) the SAME grid is row-partitioned
 over the ranks (strong scaling), halo rows travelling by RCCL send/recv inside the engine.
 
-Rank 0 prints ONE JSON line; see the task contract for its keys.  `roofline.achieved` is the
-algorithmic traffic (72 B per lattice update: 9 fp32 reads + 9 fp32 writes) divided by the
-step kernel's device time measured with HIP events on the engine's compute stream.
+Timing: W untimed warm-up steps, then an untimed pre-warm until the device has been busy for
+LBM_BENCH_PREWARM_S (0.3 s: a cold GPU clocks up over the first ~0.1 s, which made a 20-step run
+15 % slower than a 200-step one), then the K-step timed region -- barrier + device sync on both
+sides, max over ranks -- LBM_BENCH_REPEATS (5) times back to back; `value`, `ms_per_step` and the
+roofline come from the MEDIAN repeat, every repeat is listed in `repeats_ms_per_step`.
+
+Rank 0 prints ONE JSON line; see the task contract for its keys.  Roofline block: `achieved` is the
+COMPULSORY traffic of one launch of the dominant kernel -- the slab's lattice read once and written
+once, 72 B per cell, however many timesteps the launch advances -- divided by the launch's device
+time (HIP events on the engine's compute stream), so `frac` = achieved / 8 TB/s is a true fraction
+of the HBM bound (<= 1).  The BASELINE metric's bandwidth (72 B per lattice UPDATE) is reported
+beside it as `algorithmic_GBps`: with k timesteps per pass over memory it is k x `achieved` and may
+exceed the peak.  `limiter` names what the PMC profile of the same kernel geometry says binds it.
 """
 import argparse
 import importlib.util
@@ -126,26 +136,60 @@ def cpu_reference(budget_steps=300):
     return None
 
 
-def pmc_traffic(nx, ny, steps_per_launch):
-    """HBM bytes per launch from a committed rocprofv3 --pmc summary, if one matches this grid
-    and kernel (profiles/pmc_traffic.json, collected as MI355X_MICROARCH.md prescribes)."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        with open(path) as fh:
-            rec = json.load(fh)
-        return rec.get(f"{nx}x{ny}/steps_per_launch={steps_per_launch}")
-    except Exception:
+def cpu_baseline_multicore(nx, ny, threads=16, budget_s=6.0):
+    """The reference's own fastest shared-memory formulation (OpenMP/d2q9-bgk.c:334: fused two-lattice SoA
+    sweep, `omp parallel for` + reduction) as restated in the oracle, on `threads` cores with the reference's
+    binding (OpenMP/env.sh:2-4: OMP_PROC_BIND=true OMP_PLACES=cores).  16 = the host-CPU share of a 1-GPU job
+    on this pool.  Reported beside the 1-core figure; test infrastructure, never the thing measured above."""
+    cli = os.path.join(ROOT, "oracle", "lbm_oracle_cli")
+    if not os.path.exists(cli):
         return None
+    threads = max(1, min(threads, os.cpu_count() or 1))
+    steps = int(max(4, min(400, budget_s * 450e6 / (nx * ny))))
+    inputs = os.path.join(ROOT, "tests", "golden", "inputs")
+    env = dict(os.environ, LBM_OUTPUT="none", LBM_ORACLE_FORM="fused", OMP_NUM_THREADS=str(threads),
+               OMP_PROC_BIND="true", OMP_PLACES="cores")
+    with tempfile.TemporaryDirectory() as tmp:
+        pf = os.path.join(tmp, "in.params")
+        with open(pf, "w") as fh:
+            fh.write(f"{nx}\n{ny}\n{steps}\n10\n0.1\n0.01\n1.85\n")
+        if os.path.exists(os.path.join(inputs, f"obstacles_{nx}x{ny}.dat")):
+            obf = os.path.join(inputs, f"obstacles_{nx}x{ny}.dat")
+        else:
+            obf = os.path.join(inputs, "obstacles_1024x1024.dat")
+            env["LBM_TILE"] = "1024x1024"
+        try:
+            out = subprocess.run([cli, pf, obf], cwd=tmp, env=env, capture_output=True, text=True, timeout=180)
+        except Exception:
+            return None
+    if out.returncode != 0:
+        return None
+    for line in out.stdout.splitlines():
+        if line.startswith("Elapsed Compute time"):
+            secs = float(line.split()[-2])
+            if secs > 0:
+                return {"value": nx * ny * steps / secs / 1e6, "unit": "MLUPS", "cores": threads, "kind": "port",
+                        "sample": f"{steps} steps of the same {nx}x{ny} grid, oracle/lbm_oracle_cli LBM_ORACLE_FORM=fused "
+                                  f"(two-lattice SoA pull sweep, the formulation of OpenMP/d2q9-bgk.c:334), "
+                                  f"OMP_NUM_THREADS={threads} OMP_PROC_BIND=true OMP_PLACES=cores, {secs:.2f} s compute"}
+    return None
 
 
-def pmc_extra(nx, ny, steps_per_launch, what):
-    """Other committed PMC figures of the same kernel and grid (profiles/pmc_traffic.json), e.g. the fraction of
-    SIMD cycles in which a VALU instruction issues."""
+def pmc_record(nx, ny, math, info):
+    """Committed rocprofv3 --pmc figures for EXACTLY this kernel geometry (profiles/pmc_traffic.json, collected as
+    MI355X_MICROARCH.md prescribes: separate passes, FETCH_SIZE x2 on gfx950), or None.  Not a measurement of this
+    run: the record names the commit and the run it came from, and is dropped when grid, math, timesteps per
+    launch, band height or cells per lane differ from what is running."""
+    key = (f"{nx}x{ny}/math={math}/steps_per_launch={info['steps_per_launch']}"
+           f"/band={info['band_rows']}/lane_cells={info['lane_cells']}")
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-            return json.load(fh).get(f"{nx}x{ny}/steps_per_launch={steps_per_launch}/{what}")
+            rec = json.load(fh).get(key)
     except Exception:
         return None
+    if rec:
+        rec = dict(rec, key=key)
+    return rec
 
 
 def main():
@@ -166,6 +210,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 as\n  python -m torch.distributed.run "
                          f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port 29500 "
                          f"bench.py --gpus {args.gpus} ...")
+    repeats = max(1, int(os.environ.get("LBM_BENCH_REPEATS", "5")))
+    prewarm_s = float(os.environ.get("LBM_BENCH_PREWARM_S", "0.3"))
 
     # stdout must carry exactly ONE JSON line, but RCCL prints a five-line version banner on the C-level stdout
     # at communicator creation (whatever NCCL_DEBUG says): keep the real stdout aside for the line and point
@@ -205,45 +251,60 @@ def main():
     printed = threading.Event()
 
     def compose_line(extras_note=None):
-        elapsed, kernel_ms, steps_per_launch, finite, workload = (main_result[k] for k in
-                                                                  ("elapsed", "kernel_ms", "spl", "finite", "workload"))
+        r = main_result
+        elapsed, kernel_ms, info = r["elapsed"], r["kernel_ms"], r["info"]
+        spl = info["steps_per_launch"]
         cells = float(nx) * float(ny)
         mlups = cells * args.steps / elapsed / 1e6
-        # per-launch algorithmic bytes: this rank's share of the grid (max over ranks = ceil)
+        # one launch of the dominant kernel sweeps this rank's slab once (max over ranks = ceil) and advances it
+        # `spl` timesteps: it must read the lattice once and write it once -- 72 B per cell whatever spl is.
         rows_per_rank = -(-ny // world)
-        # one launch of the dominant kernel advances `steps_per_launch` timesteps (the two-step
-        # kernel reads and writes the lattice once per TWO updates): algorithmic bytes per launch =
-        # 72 B x cells x steps_per_launch, launch duration = steps_per_launch x time per step
-        algo_bytes = BYTES_PER_UPDATE * nx * rows_per_rank * steps_per_launch
-        launch_ms = kernel_ms * steps_per_launch
-        achieved = algo_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-        traffic = pmc_traffic(nx, ny, steps_per_launch) if world == 1 else None
-        kernel_name = {2: "lbm::step2_stream", 1: "lbm::step_vec4"}.get(steps_per_launch, "lbm::step_tile")
+        compulsory_bytes = BYTES_PER_UPDATE * nx * rows_per_rank
+        launch_ms = kernel_ms * spl
+        achieved = compulsory_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        pmc = pmc_record(nx, ny, args.math, info) if world == 1 else None
+        kernel_name = {3: "lbm::step3_stream", 2: "lbm::step2_stream", 1: "lbm::step_vec4"}.get(spl, "lbm::step_tile")
+        if info["lane_cells"] == 0 and spl > 1:
+            kernel_name = "lbm::step_tile"
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": pmc.get("traffic_bytes_per_launch") if pmc else None,
+                "kernel": kernel_name, "steps_per_launch": spl, "launch_ms": launch_ms,
+                "kernel_ms_per_step": kernel_ms,
+                "compulsory_bytes_per_launch": compulsory_bytes,
+                "algorithmic_bytes_per_launch": compulsory_bytes * spl,
+                "algorithmic_GBps": achieved * spl,
+                "geometry": {"band_rows": info["band_rows"], "lane_cells": info["lane_cells"],
+                             "nontemporal_stores": info["nontemporal"]},
+                "note": ("achieved = compulsory bytes of one launch (the slab read once + written once, 72 B per cell) / "
+                         "launch time, so frac <= 1 is a fraction of the HBM bound; algorithmic_GBps = 72 B per lattice "
+                         f"UPDATE x updates / time = {spl} x achieved (the BASELINE metric; temporal blocking x{spl}: each "
+                         "byte moved serves that many updates, so it may exceed the peak)")}
+        if pmc:
+            t = pmc.get("traffic_bytes_per_launch")
+            roof["traffic_source"] = (f"committed rocprofv3 --pmc profile {pmc.get('source')} at commit {pmc.get('commit')}, "
+                                      f"same grid / math / kernel geometry ({pmc['key']}); NOT measured in this run")
+            if t and launch_ms > 0:
+                roof["traffic_over_compulsory"] = t / compulsory_bytes
+                roof["traffic_GBps_at_this_runs_launch_time"] = t / (launch_ms * 1e-3) / 1e9
+            if pmc.get("valu_busy") is not None:
+                roof["limiter"] = {"valu_busy": pmc["valu_busy"], "what": pmc.get("limiter_note"),
+                                   "source": "same committed profile"}
         line = {
             "metric": "MLUPS", "value": mlups, "unit": "MLUPS (million lattice updates/s)",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"D2Q9-BGK timestep loop, {workload}, uniform-equilibrium start",
+            "config": {"workload": f"D2Q9-BGK timestep loop, {r['workload']}, uniform-equilibrium start",
                        "grid": f"{nx}x{ny}", "math": args.math,
-                       "timesteps_per_memory_pass": steps_per_launch,
+                       "timesteps_per_memory_pass": spl,
                        "decomposition": f"{world} row slab(s), RCCL halo send/recv" if world > 1
                        else "single slab, periodic in-kernel"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": kernel_name, "steps_per_launch": steps_per_launch,
-                         "launch_ms": launch_ms, "kernel_ms_per_step": kernel_ms,
-                         "algorithmic_bytes_per_launch": algo_bytes,
-                         "traffic_GBps": (traffic / (launch_ms * 1e-3) / 1e9) if traffic else None,
-                         "valu_busy_pmc": pmc_extra(nx, ny, steps_per_launch, "valu_busy") if world == 1 else None,
-                         "note": ("achieved = algorithmic bytes (72 B per lattice update) / launch time; "
-                                  "the two-step kernel reads and writes the lattice once per TWO updates, "
-                                  "so achieved may exceed the HBM peak while the bytes actually moved "
-                                  "(traffic: rocprofv3 PMC at the L2-fabric boundary, Infinity-Cache hits "
-                                  "included) stay below the algorithmic count; at that point the kernel is bound by VALU issue "
-                                  "(valu_busy_pmc = share of SIMD cycles issuing a VALU instruction)") if steps_per_launch == 2
-                         else "achieved = algorithmic bytes (72 B per lattice update) / launch time"},
-            "results_finite": finite,
+            "timing": {"repeats": len(r["repeats"]), "statistic": "median",
+                       "repeats_ms_per_step": [e / args.steps * 1e3 for e in r["repeats"]],
+                       "prewarm_steps_untimed": r["prewarm_steps"], "prewarm_target_s": prewarm_s},
+            "roofline": roof,
+            "results_finite": r["finite"],
         }
         if check:
             line["multi_gpu_check"] = dict(check)
@@ -258,14 +319,22 @@ def main():
             printed.set()
             os.write(real_stdout, (json.dumps(line) + "\n").encode())
 
+    verify_wanted = [False]
+
     def extras_watchdog():
         """The headline measurement is done; the verification and the extra configurations that follow must not
-        be able to lose it.  If they have not finished in time, rank 0 prints the line with what it has and
-        every rank leaves (a blocked HIP / RCCL call cannot be interrupted from Python)."""
+        be able to lose it -- nor may a hang there pass for success.  If they have not finished in time, rank 0
+        prints the line with what it has, marked as failed where a verification was pending, and EVERY rank exits
+        non-zero (a blocked HIP / RCCL call cannot be interrupted from Python)."""
         if rank == 0:
-            print_once(compose_line("verification / extra configurations did not finish within "
-                                    f"{extras_timeout:.0f} s and were abandoned"))
-        os._exit(0 if rank == 0 else 3)
+            note = (f"verification / extra configurations did not finish within {extras_timeout:.0f} s and were abandoned")
+            if verify_wanted[0] and "fields_bitwise_equal_to_single_gpu_run" not in check:
+                check.update({"error": "timeout", "fields_bitwise_equal_to_single_gpu_run": False})
+                main_result["finite"] = False
+            line = compose_line(note)
+            line["extras_failed"] = True
+            print_once(line)
+        os._exit(4)
 
     extras_timeout = float(os.environ.get("LBM_BENCH_EXTRA_TIMEOUT", "300"))
 
@@ -296,11 +365,12 @@ def main():
     watchdog = threading.Timer(extras_timeout, extras_watchdog)
     watchdog.daemon = True
 
-    def measure(gx, gy, steps, warmup, verify=False, headline=False):
-        """One timed run of `steps` timesteps of a gx x gy grid after `warmup` untimed ones: barrier +
-        device sync on both sides, max over ranks.  Returns (seconds, kernel ms per step,
-        steps_per_launch, av_vels finite, workload description)."""
-        p, ob, workload = synthetic_case(lbm, gx, gy, warmup + steps)
+    def measure(gx, gy, steps, warmup, verify=False, headline=False, n_repeats=1, prewarm=0.0):
+        """`warmup` untimed timesteps of a gx x gy grid, an untimed pre-warm of about `prewarm` seconds, then
+        `n_repeats` timed regions of `steps` timesteps each: barrier + device sync on both sides, max over
+        ranks.  Returns the median region: (seconds, kernel ms per step, engine info, av_vels finite, workload)."""
+        prewarm_cap = 40000
+        p, ob, workload = synthetic_case(lbm, gx, gy, warmup + prewarm_cap + n_repeats * steps)
         eng = make_engine(p, ob)
 
         def fence():
@@ -310,35 +380,72 @@ def main():
                 dist.barrier()
                 torch.cuda.synchronize()
 
-        if warmup > 0:
-            eng.run(warmup)
+        def agree(v):   # every rank must run the same number of steps: take rank 0's view
+            if not use_rank_api:
+                return v
+            t = torch.tensor([float(v)], dtype=torch.float64, device="cuda")
+            dist.broadcast(t, src=0)
+            return float(t[0])
+
+        done = 0
         fence()
         t0 = time.perf_counter()
-        kernel_ms = eng.run_timed(steps)
+        if warmup > 0:
+            eng.run(warmup)
+            done += warmup
         fence()
-        elapsed = time.perf_counter() - t0
-        if use_rank_api:
-            t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed, kernel_ms = float(t[0]), float(t[1])
-        av = eng.av_vels(warmup + steps)          # forces the cross-rank reduce too
+        spent = time.perf_counter() - t0
+        prewarm_steps = 0
+        if prewarm > 0:
+            # chunks of `steps` until the device has been busy for `prewarm` seconds (clock ramp-up)
+            per_step = agree(spent / max(warmup, 1)) if warmup > 0 else 0.0
+            while agree(spent) < prewarm and prewarm_steps + steps <= prewarm_cap:
+                chunk = steps
+                if per_step > 0:
+                    chunk = int(min(max(steps, (prewarm - spent) / per_step), prewarm_cap - prewarm_steps))
+                    chunk = int(agree(chunk))
+                t1 = time.perf_counter()
+                eng.run(chunk)
+                fence()
+                dt = time.perf_counter() - t1
+                spent += dt
+                per_step = agree(dt / chunk)
+                prewarm_steps += chunk
+            done += prewarm_steps
+        runs = []
+        for _ in range(n_repeats):
+            fence()
+            t0 = time.perf_counter()
+            kernel_ms = eng.run_timed(steps)
+            fence()
+            elapsed = time.perf_counter() - t0
+            if use_rank_api:
+                t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                elapsed, kernel_ms = float(t[0]), float(t[1])
+            runs.append((elapsed, kernel_ms))
+            done += steps
+        elapsed, kernel_ms = sorted(runs)[len(runs) // 2]
+        av = eng.av_vels(done)          # forces the cross-rank reduce too
         finite = bool(np.isfinite(av).all())
-        spl = eng.info()["steps_per_launch"]
+        info = eng.info()
         if headline:
-            main_result.update(elapsed=elapsed, kernel_ms=kernel_ms, spl=spl, finite=finite, workload=workload)
+            main_result.update(elapsed=elapsed, kernel_ms=kernel_ms, info=info, finite=finite, workload=workload,
+                               repeats=[e for e, _ in runs], prewarm_steps=prewarm_steps)
+            verify_wanted[0] = verify
             watchdog.start()
         if verify:
             try:
-                verify_against_single_gpu(p, ob, eng, av, warmup + steps)
+                verify_against_single_gpu(p, ob, eng, av, done)
             except Exception as exc:
-                check["error"] = str(exc)
+                check.update({"error": str(exc), "fields_bitwise_equal_to_single_gpu_run": False})
         eng.close()
-        return elapsed, kernel_ms, spl, finite, workload
+        return elapsed, kernel_ms, info, finite, workload
 
     # (outside the timed region) a multi-rank result is checked against a single-GPU run of the same workload
     verify = use_rank_api and (world > 1 or os.environ.get("LBM_FORCE_HALO") == "1") and \
         os.environ.get("LBM_BENCH_VERIFY", "1") != "0"
-    measure(nx, ny, args.steps, args.warmup, verify, headline=True)
+    measure(nx, ny, args.steps, args.warmup, verify, headline=True, n_repeats=repeats, prewarm=prewarm_s)
 
     # BASELINE.json's other named configurations, measured the same way (every rank takes part):
     # the reference's own 1024x1024 data set (20 000 steps in the reference; Infinity-Cache resident,
@@ -354,22 +461,28 @@ def main():
             if (gx, gy) == (nx, ny):
                 continue
             try:
-                dt, k_ms, spl, fin, _ = measure(gx, gy, st, wu)
+                dt, k_ms, inf, fin, _ = measure(gx, gy, st, wu, n_repeats=3)
                 also[f"{gx}x{gy}"] = {"value": gx * gy * st / dt / 1e6, "unit": "MLUPS", "n_gpus": args.gpus,
                                       "ms_per_step": dt / st * 1e3, "kernel_ms_per_step": k_ms, "steps": st,
-                                      "warmup": wu, "steps_per_launch": spl, "results_finite": fin, "note": note}
+                                      "warmup": wu, "repeats": 3, "steps_per_launch": inf["steps_per_launch"],
+                                      "band_rows": inf["band_rows"], "lane_cells": inf["lane_cells"],
+                                      "results_finite": fin, "note": note}
             except Exception as exc:            # never lose the main line over an extra one
                 also[f"{gx}x{gy}"] = {"error": str(exc)}
                 if use_rank_api:
                     break                       # ranks may have diverged: stop issuing collectives
 
     watchdog.cancel()
+    failed = bool(check) and not check.get("fields_bitwise_equal_to_single_gpu_run", False)
     if rank == 0:
         line = compose_line()
         if world == 1 and not args.no_cpu_baseline:
             base = cpu_baseline(nx, ny)
             if base:
                 line["cpu_baseline"] = base
+            multi = cpu_baseline_multicore(nx, ny)
+            if multi:
+                line["cpu_baseline_multicore"] = multi
             ref = cpu_reference()
             if ref:
                 line["cpu_reference_1024x1024"] = ref
@@ -377,6 +490,8 @@ def main():
 
     if use_rank_api:
         dist.destroy_process_group()
+    if failed:
+        sys.exit(5)     # the multi-rank result differs from the single-GPU run: not a successful bench
 
 
 if __name__ == "__main__":

@@ -71,9 +71,13 @@ typedef struct {
   int    math_mode;      /* LBM_MATH_EXACT or LBM_MATH_FAST */
   int    world_rank;     /* rank of this context in a multi-process run (0 otherwise) */
   int    world_size;     /* number of processes sharing the grid (1 otherwise) */
-  int    steps_per_launch; /* timesteps one launch of the main kernel advances: 2 when the
-                              two-steps-per-pass kernel is active (large grids), else 1 */
+  int    steps_per_launch; /* timesteps one launch of the main kernel advances: 2 or 3 for the
+                              stream kernels (large grids), 3-4 for the LDS-tile kernel, else 1 */
   int    halo_mode;      /* LBM_HALO_SYNC or LBM_HALO_STALE (meaningful with several slabs / ranks) */
+  int    band_rows;      /* launch geometry of the multi-step stream kernel: rows one wave sweeps ... */
+  int    lane_cells;     /* ... and cells per lane (4 or 2); 0 / 0 when another kernel is the main one */
+  int    nontemporal;    /* 1: the step kernels store with the nontemporal hint */
+  int    graph_steps;    /* timesteps one captured hipGraph replays (0: loop issued launch by launch) */
 } lbm_info;
 
 /* ---- error handling -------------------------------------------------------------------- */
@@ -124,6 +128,34 @@ int      lbm_rccl_unique_id(void* id_out);
 lbm_ctx* lbm_create_rank(const lbm_params* params, const int* obstacles, const float* cells_aos,
                          int rank, int world_size, const void* unique_id, int device,
                          int math_mode);
+
+/*
+ * The same, without the global map on every rank -- the reference's scatter (rank 0 parses, every rank
+ * receives only its rows, MPI_Waitall/d2q9-bgk.c:794-842):
+ *   obstacle_rows  : int[(row_count + 2*LBM_MASK_HALO_ROWS) * nx] -- the rows lbm_partition_rows gives this
+ *                    rank, preceded and followed by LBM_MASK_HALO_ROWS periodic neighbour rows (global rows
+ *                    row_first - LBM_MASK_HALO_ROWS ... row_first + row_count + LBM_MASK_HALO_ROWS - 1, folded
+ *                    into [0, ny)): a multi-step pass relaxes that many rows beyond the slab redundantly;
+ *   cells_rows_aos : float[row_count * nx * 9], this rank's rows only, or NULL (uniform equilibrium).
+ * The mask is built on the device; the fluid-cell count (av_velocity's divisor) is a device reduction over the
+ * owned rows summed over the ranks by one all-reduce.  lbm_create and lbm_create_rank count the same way.
+ */
+#define LBM_MASK_HALO_ROWS 2
+lbm_ctx* lbm_create_rank_rows(const lbm_params* params, const int* obstacle_rows, const float* cells_rows_aos,
+                              int rank, int world_size, const void* unique_id, int device,
+                              int math_mode);
+
+/*
+ * Obstacles given as a small tile repeated periodically over the grid: cell (x, y) is blocked iff the tile's cell
+ * (x mod tile_nx, y mod tile_ny) is (tile: int[tile_ny*tile_nx]).  This is how BASELINE.md section 4 defines the
+ * synthetic 8192x8192 and 16384x16384 grids (the reference's 1024x1024 map tiled); the mask is expanded on the
+ * device from the tile, so a 16384x16384 run never holds a 1 GiB int map on the host.
+ */
+lbm_ctx* lbm_create_tiled(const lbm_params* params, const int* tile, int tile_nx, int tile_ny,
+                          const float* cells_aos, int n_gpus, int math_mode);
+lbm_ctx* lbm_create_rank_tiled(const lbm_params* params, const int* tile, int tile_nx, int tile_ny,
+                               int rank, int world_size, const void* unique_id, int device,
+                               int math_mode);
 
 void     lbm_destroy(lbm_ctx* ctx);
 int      lbm_get_info(const lbm_ctx* ctx, lbm_info* out);

@@ -31,6 +31,7 @@ MATH_EXACT = 0
 MATH_FAST = 1
 _MATH = {"exact": MATH_EXACT, "fast": MATH_FAST, MATH_EXACT: MATH_EXACT, MATH_FAST: MATH_FAST}
 RCCL_ID_BYTES = 128
+MASK_HALO_ROWS = 2        # LBM_MASK_HALO_ROWS of include/lbm_hip.h
 HALO_SYNC = 0
 HALO_STALE = 1
 _HALO = {"sync": HALO_SYNC, "stale": HALO_STALE, HALO_SYNC: HALO_SYNC, HALO_STALE: HALO_STALE}
@@ -38,7 +39,8 @@ _HALO = {"sync": HALO_SYNC, "stale": HALO_STALE, HALO_SYNC: HALO_SYNC, HALO_STAL
 # every symbol include/lbm_hip.h declares (tests check the .so exports them all)
 ABI_SYMBOLS = (
     "lbm_set_error_mode", "lbm_last_error", "lbm_version", "lbm_device_count",
-    "lbm_partition_rows", "lbm_create", "lbm_rccl_unique_id", "lbm_create_rank", "lbm_destroy",
+    "lbm_partition_rows", "lbm_create", "lbm_rccl_unique_id", "lbm_create_rank", "lbm_create_rank_rows",
+    "lbm_create_tiled", "lbm_create_rank_tiled", "lbm_destroy",
     "lbm_get_info", "lbm_set_halo_mode", "lbm_run", "lbm_sync", "lbm_run_timed", "lbm_read_av_vels", "lbm_read_cells",
     "lbm_read_final_state", "lbm_av_velocity", "lbm_total_density", "lbm_calc_reynolds",
 )
@@ -59,7 +61,8 @@ class _CInfo(ctypes.Structure):
                 ("fluid_cells", ctypes.c_int), ("steps_done", ctypes.c_int),
                 ("math_mode", ctypes.c_int), ("world_rank", ctypes.c_int),
                 ("world_size", ctypes.c_int), ("steps_per_launch", ctypes.c_int),
-                ("halo_mode", ctypes.c_int)]
+                ("halo_mode", ctypes.c_int), ("band_rows", ctypes.c_int), ("lane_cells", ctypes.c_int),
+                ("nontemporal", ctypes.c_int), ("graph_steps", ctypes.c_int)]
 
 
 @dataclass
@@ -111,6 +114,11 @@ def load_library() -> ctypes.CDLL:
     lib.lbm_rccl_unique_id.argtypes = [P]; lib.lbm_rccl_unique_id.restype = I
     lib.lbm_create_rank.argtypes = [ctypes.POINTER(_CParams), P, P, I, I, P, I, I]
     lib.lbm_create_rank.restype = P
+    lib.lbm_create_rank_rows.argtypes = [ctypes.POINTER(_CParams), P, P, I, I, P, I, I]
+    lib.lbm_create_rank_rows.restype = P
+    lib.lbm_create_tiled.argtypes = [ctypes.POINTER(_CParams), P, I, I, P, I, I]; lib.lbm_create_tiled.restype = P
+    lib.lbm_create_rank_tiled.argtypes = [ctypes.POINTER(_CParams), P, I, I, I, I, P, I, I]
+    lib.lbm_create_rank_tiled.restype = P
     lib.lbm_destroy.argtypes = [P]; lib.lbm_destroy.restype = None
     lib.lbm_get_info.argtypes = [P, ctypes.POINTER(_CInfo)]; lib.lbm_get_info.restype = I
     lib.lbm_set_halo_mode.argtypes = [P, I]; lib.lbm_set_halo_mode.restype = I
@@ -163,28 +171,56 @@ class Engine:
 
     def __init__(self, params: Params, obstacles: np.ndarray, cells: np.ndarray | None = None,
                  n_gpus: int = 1, math: str | int = "exact", *, rank: int | None = None,
-                 world_size: int | None = None, unique_id: bytes | None = None, device: int = 0):
+                 world_size: int | None = None, unique_id: bytes | None = None, device: int = 0,
+                 tiled: bool = False, local_rows: bool = False):
+        """obstacles: the global (ny, nx) map; with tiled=True a small (tile_ny, tile_nx) map repeated
+        periodically over the grid (lbm_create_tiled / lbm_create_rank_tiled: the mask is expanded on the
+        device); with local_rows=True (rank form only) this rank's rows preceded and followed by
+        MASK_HALO_ROWS periodic neighbour rows, and `cells` this rank's rows only (lbm_create_rank_rows)."""
         self.lib = load_library()
         self.params = params
         if params.nx < 1 or params.ny < 2 or params.max_iters < 0:
             raise LbmError("lbm_create: invalid parameters")
         obstacles = np.ascontiguousarray(obstacles, dtype=np.int32)
-        if obstacles.size != params.nx * params.ny:
-            raise LbmError("lbm_create: obstacle map does not match nx*ny")
-        obstacles = obstacles.reshape(params.ny, params.nx)
+        cell_rows = params.ny
+        if tiled:
+            if obstacles.ndim != 2:
+                raise LbmError("lbm_create_tiled: the tile must be a 2-D map")
+        elif local_rows:
+            if rank is None:
+                raise LbmError("local_rows needs the rank form")
+            _, cell_rows = partition_rows(params.ny, world_size, rank)
+            if obstacles.size != params.nx * (cell_rows + 2 * MASK_HALO_ROWS):
+                raise LbmError("lbm_create_rank_rows: obstacle rows do not match (row_count + 2*MASK_HALO_ROWS)*nx")
+        else:
+            if obstacles.size != params.nx * params.ny:
+                raise LbmError("lbm_create: obstacle map does not match nx*ny")
+            obstacles = obstacles.reshape(params.ny, params.nx)
         self._obstacles = obstacles
         cptr = None
         if cells is not None:
             cells = np.ascontiguousarray(cells, dtype=np.float32)
-            if cells.size != params.nx * params.ny * 9:
+            if cells.size != params.nx * cell_rows * 9:
                 raise LbmError("lbm_create: cells do not match nx*ny*9")
-            cells = cells.reshape(params.ny, params.nx, 9)
+            cells = cells.reshape(cell_rows, params.nx, 9)
             cptr = cells.ctypes.data
         cp = params._c()
+        idbuf = ctypes.create_string_buffer(unique_id, RCCL_ID_BYTES) if unique_id else None
         if rank is None:
-            h = self.lib.lbm_create(ctypes.byref(cp), obstacles.ctypes.data, cptr, n_gpus, _MATH[math])
+            if tiled:
+                h = self.lib.lbm_create_tiled(ctypes.byref(cp), obstacles.ctypes.data, obstacles.shape[1],
+                                              obstacles.shape[0], cptr, n_gpus, _MATH[math])
+            else:
+                h = self.lib.lbm_create(ctypes.byref(cp), obstacles.ctypes.data, cptr, n_gpus, _MATH[math])
+        elif tiled:
+            if cells is not None:
+                raise LbmError("lbm_create_rank_tiled starts from the uniform equilibrium")
+            h = self.lib.lbm_create_rank_tiled(ctypes.byref(cp), obstacles.ctypes.data, obstacles.shape[1],
+                                               obstacles.shape[0], rank, world_size, idbuf, device, _MATH[math])
+        elif local_rows:
+            h = self.lib.lbm_create_rank_rows(ctypes.byref(cp), obstacles.ctypes.data, cptr, rank,
+                                              world_size, idbuf, device, _MATH[math])
         else:
-            idbuf = ctypes.create_string_buffer(unique_id, RCCL_ID_BYTES) if unique_id else None
             h = self.lib.lbm_create_rank(ctypes.byref(cp), obstacles.ctypes.data, cptr, rank,
                                          world_size, idbuf, device, _MATH[math])
         if not h:

@@ -76,10 +76,11 @@ struct Slab {
   int device = 0;
   int row_first = 0;  // global row of slab row 0
   int rows = 0;       // owned rows
-  int accel_row = lbm::kNoRow;  // slab row (may be a halo row: -1 or rows) holding global row ny-2
+  int accel_row = lbm::kNoRow;  // slab row (may be a halo row) holding global row ny-2
+  int accel_row2 = lbm::kNoRow; // its second periodic image among the halo rows (a ring of ONE slab with 3-step passes)
   float* lat_alloc[2] = {nullptr, nullptr};  // (rows + 2*kHaloRows) x row_pitch each
   float* lat[2] = {nullptr, nullptr};        // row 0 of each lattice (= lat_alloc + kHaloRows rows)
-  unsigned char* mask_alloc = nullptr;       // (rows + 2) x pitch: one halo row below and above
+  unsigned char* mask_alloc = nullptr;       // (rows + 2*kMaskHalo) x pitch: neighbour rows below and above
   unsigned char* mask = nullptr;             // row 0 of the mask
   float* partials = nullptr;  // kPartSlots x part_stride
   double* tot_u = nullptr;    // capacity entries: per-step sum of |u| over this slab
@@ -96,6 +97,7 @@ struct Slab {
   lbm::SlotCounts slot_counts;  // partials written into each buffered slot (launch geometries differ)
   int blocks_main = 0;      // interior rows (or all rows in HALO_SELF)
   int blocks_boundary = 0;  // rows 0 and rows-1 (halo modes)
+  long fluid_cells = 0;     // non-blocked cells among the owned rows
 };
 
 constexpr int kSumBlocks = 1024;
@@ -112,7 +114,20 @@ const TileShape kTileShapes[] = {
     LBM_TILE_SHAPE(64, 8, 2, 704),
 };
 constexpr int kTileShapeCount = (int)(sizeof(kTileShapes) / sizeof(kTileShapes[0]));
-constexpr int kHaloRows = 2;  // halo rows kept below and above every slab (two-step kernel needs 2)
+constexpr int kHaloRows = 3;  // halo rows kept below and above every slab (a K-step pass reads K rows beyond the slab)
+constexpr int kMaskHalo = LBM_MASK_HALO_ROWS;  // mask rows kept beyond the slab: a K-step pass relaxes K-1 halo rows redundantly
+static_assert(kMaskHalo == kHaloRows - 1, "mask halo");
+
+// where the obstacle flags come from (the reference: initialise() fills int[ny*nx] on rank 0 and, in the MPI variants,
+// sends every rank its rows, MPI_Waitall/d2q9-bgk.c:794-842)
+enum ObstacleKind { OBST_GLOBAL = 0, OBST_ROWS = 1, OBST_TILE = 2 };
+struct ObstacleSource {
+  int kind;
+  const int* data;  // GLOBAL: int[ny*nx]; ROWS: this context's rows with kMaskHalo periodic neighbour rows each side;
+                    // TILE: int[tile_ny*tile_nx], repeated periodically over the grid
+  int tile_nx, tile_ny;
+  bool local_cells;  // cells_aos holds only this context's rows (ROWS form)
+};
 
 // One host thread per slab for the issue loop of a one-process multi-GPU run: a pass enqueues
 // ~10 runtime calls per slab, which a single thread issues at 25-30 us per slab -- more than an
@@ -210,7 +225,11 @@ struct lbm_ctx {
   int neigh = 0;  // step_vec4 NEIGH flavour (LBM_NEIGH overrides)
   int nts = 1;    // nontemporal stores (LBM_NTS overrides)
   int snake = 0;  // alternate the sweep direction every step (LBM_SNAKE overrides)
-  int fuse2 = 0;  // two timesteps per pass (step2_stream) when a single periodic slab allows it
+  int fuse2 = 0;  // several timesteps per pass over memory (the stream kernels) where the slabs allow it
+  int pass_steps = 2;  // ... how many: 2 or 3 (LBM_PASS_STEPS)
+  int prefetch = 0;    // stream kernel: request the next row before relaxing the current one (LBM_PREFETCH)
+  int xcd_chunk = 0;   // stream kernel: strips per XCD chunk (LBM_XCD_CHUNK; 0 = plain workgroup order)
+  int use_stepk = 0;   // two-step passes through stepk_stream<K=2> instead of step2_stream (LBM_STEPK; experiments)
   int band_rows = 8, n_strips = 0;  // step2_stream geometry: band height, waves across x
   int lane_cells = 4;               // cells per lane in step2_stream (4 or 2; LBM_LANE_CELLS)
   SlabTeam* team = nullptr;         // one issuing thread per slab (one-process multi-GPU), or null
@@ -310,6 +329,8 @@ int launch_step2(lbm_ctx* c, int s, hipStream_t stream, int row_first, int row_e
   a.a2 = c->p.density * c->p.accel / 36.f;
   a.partials1 = sl.partials + (long)c->slot_fill * c->part_stride + part_offset;
   a.partials2 = a.partials1 + c->part_stride;
+  static const int stagger = env_int("LBM_STAGGER", 0);
+  a.stagger = stagger;
   const int waves = c->n_strips * band_count;
   typedef void (*fn)(const lbm::Step2Args);
   // [math][nontemporal stores][cells per lane: 0 -> 4, 1 -> 2]
@@ -323,6 +344,68 @@ int launch_step2(lbm_ctx* c, int s, hipStream_t stream, int row_first, int row_e
   else hipLaunchKernelGGL(kernel, dim3(waves), dim3(64), 0, stream, a);
   HIP_TRY(LBM_FAILURE, hipGetLastError());
   return LBM_SUCCESS;
+}
+
+// k (2..3) timesteps in one pass over the rows [row_first, row_end) of slab s (4 cells per lane), cut into band_count
+// bands of band_rows rows that start band_pitch rows apart; partials of step t+j go to slot slot_fill + j
+int launch_stepk(lbm_ctx* c, int s, hipStream_t stream, int k, int row_first, int row_end, int band_rows,
+                 int band_pitch, int band_count, int part_offset, bool accel_after, hipEvent_t done = nullptr) {
+  Slab& sl = c->slab[s];
+  if (band_count <= 0) return LBM_SUCCESS;
+  lbm::StepKArgs a;
+  a.src = sl.lat[c->cur];
+  a.dst = sl.lat[c->cur ^ 1];
+  a.mask = sl.mask;
+  a.plane_stride = c->plane_stride;
+  a.row_pitch = c->row_pitch;
+  a.pitch = c->pitch;
+  a.nx = c->p.nx;
+  a.rows = sl.rows;
+  a.wrap = (c->halo == HALO_SELF) ? 1 : 0;
+  a.band_rows = band_rows;
+  a.row_first = row_first;
+  a.band_pitch = band_pitch;
+  a.row_end = row_end;
+  a.n_strips = c->n_strips;
+  a.n_bands = band_count;
+  a.chunk = c->xcd_chunk;
+  a.accel_row = sl.accel_row;
+  a.accel_row2 = sl.accel_row2;
+  a.accel_after = accel_after ? 1 : 0;
+  a.omega = c->p.omega;
+  a.a1 = c->p.density * c->p.accel / 9.f;
+  a.a2 = c->p.density * c->p.accel / 36.f;
+  a.partials = sl.partials + (long)c->slot_fill * c->part_stride + part_offset;
+  a.slot_stride = c->part_stride;
+  int waves = c->n_strips * band_count;
+  if (a.chunk > 0) {
+    const int chunks = band_count * ceil_div(c->n_strips, a.chunk);
+    waves = 8 * ceil_div(chunks, 8) * a.chunk;
+  }
+  typedef void (*fn)(const lbm::StepKArgs);
+  // [math][nontemporal stores][k - 2][prefetch]
+  static const fn table[2][2][2][2] = {
+      {{{lbm::stepk_stream<0, false, 4, 2, false>, lbm::stepk_stream<0, false, 4, 2, true>},
+        {lbm::stepk_stream<0, false, 4, 3, false>, lbm::stepk_stream<0, false, 4, 3, true>}},
+       {{lbm::stepk_stream<0, true, 4, 2, false>, lbm::stepk_stream<0, true, 4, 2, true>},
+        {lbm::stepk_stream<0, true, 4, 3, false>, lbm::stepk_stream<0, true, 4, 3, true>}}},
+      {{{lbm::stepk_stream<1, false, 4, 2, false>, lbm::stepk_stream<1, false, 4, 2, true>},
+        {lbm::stepk_stream<1, false, 4, 3, false>, lbm::stepk_stream<1, false, 4, 3, true>}},
+       {{lbm::stepk_stream<1, true, 4, 2, false>, lbm::stepk_stream<1, true, 4, 2, true>},
+        {lbm::stepk_stream<1, true, 4, 3, false>, lbm::stepk_stream<1, true, 4, 3, true>}}}};
+  const fn kernel = table[c->math_mode == LBM_MATH_EXACT ? 0 : 1][c->nts][k - 2][c->prefetch ? 1 : 0];
+  if (done) hipExtLaunchKernelGGL(kernel, dim3(waves), dim3(64), 0, stream, nullptr, done, 0, a);
+  else hipLaunchKernelGGL(kernel, dim3(waves), dim3(64), 0, stream, a);
+  HIP_TRY(LBM_FAILURE, hipGetLastError());
+  return LBM_SUCCESS;
+}
+
+// the stream kernel for a k-step pass: the 2-cells-per-lane form exists for k = 2 only (step2_stream)
+int launch_pass(lbm_ctx* c, int s, hipStream_t stream, int k, int row_first, int row_end, int band_rows,
+                int band_pitch, int band_count, int part_offset, bool accel_after, hipEvent_t done = nullptr) {
+  if (c->lane_cells == 4 && (k > 2 || c->prefetch || c->xcd_chunk || c->use_stepk))
+    return launch_stepk(c, s, stream, k, row_first, row_end, band_rows, band_pitch, band_count, part_offset, accel_after, done);
+  return launch_step2(c, s, stream, row_first, row_end, band_rows, band_pitch, band_count, part_offset, accel_after, done);
 }
 
 int tile_count_for(const lbm_params* p, int shape) {
@@ -495,7 +578,7 @@ int capture_chunk(lbm_ctx* c, hipGraphExec_t* out) {
       rc = launch_tile(c, sl.compute, adv, true);
       n_part = tile_count(c);
     } else if (c->fuse2) {
-      rc = launch_step2(c, 0, sl.compute, 0, sl.rows, c->band_rows, c->band_rows, ceil_div(sl.rows, c->band_rows), 0, true);
+      rc = launch_pass(c, 0, sl.compute, 2, 0, sl.rows, c->band_rows, c->band_rows, ceil_div(sl.rows, c->band_rows), 0, true);
       n_part = c->n_strips * ceil_div(sl.rows, c->band_rows);
     } else {
       rc = launch_step(c, 0, sl.compute, 0, 1, sl.rows, 0, true);
@@ -619,22 +702,24 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
         return LBM_SUCCESS;
       }) != LBM_SUCCESS)
     return LBM_FAILURE;
-  // halo depth: the two-step kernel reads two rows beyond the slab
-  const int depth = c->fuse2 ? 2 : 1;
+  // halo depth: a K-step pass reads K rows beyond the slab
+  const int depth = c->fuse2 ? c->pass_steps : 1;
   if (halo && exchange_halos(c, depth, c->cur, c->cur, -1) != LBM_SUCCESS) return LBM_FAILURE;
 
-  // macro steps: two timesteps per pass where enabled and at least two remain, else one
+  // macro steps: pass_steps timesteps per pass where enabled and that many remain, else two, else one
   int flushed_upto = c->steps_done;
   int t_first = 0;
   if (!halo && c->use_graph) {
     if (replay_chunks(c, n_steps, flushed_upto, &t_first) != LBM_SUCCESS) return LBM_FAILURE;
     flushed_upto += t_first;
   }
+  const int slots_per_pass = c->tile_steps > c->pass_steps ? c->tile_steps : c->pass_steps;
   int m = 0;  // macro step counter (event parity)
   for (int t = t_first; t < n_steps; m++) {
     const int tile = (!halo && c->tile_steps) ? (c->tile_steps < n_steps - t ? c->tile_steps : n_steps - t) : 0;
-    const bool two = !tile && c->fuse2 && (t + 1 < n_steps);
-    const int adv = tile ? tile : (two ? 2 : 1);
+    // timesteps of this pass through the stream kernel (0: another kernel)
+    const int k = (!tile && c->fuse2 && n_steps - t >= 2) ? (n_steps - t >= c->pass_steps ? c->pass_steps : 2) : 0;
+    const int adv = tile ? tile : (k ? k : 1);
     const bool last = (t + adv == n_steps);
     // phase 1: rows that touch no halo row (or the whole slab) on the compute streams
     if (for_slabs(c, [&](int s) -> int {
@@ -645,10 +730,10 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
           hipEvent_t done = (halo && ext_events) ? sl.ev_interior[m & 1] : nullptr;  // I(m) done
           if (tile) {
             if (launch_tile(c, sl.compute, tile, !last) != LBM_SUCCESS) return LBM_FAILURE;
-          } else if (two) {
-            const int r0 = halo ? 2 : 0, r1 = halo ? sl.rows - 2 : sl.rows;
-            if (launch_step2(c, s, sl.compute, r0, r1, c->band_rows, c->band_rows, ceil_div(r1 - r0, c->band_rows), 0,
-                             !last, done) != LBM_SUCCESS)
+          } else if (k) {
+            const int r0 = halo ? k : 0, r1 = halo ? sl.rows - k : sl.rows;
+            if (launch_pass(c, s, sl.compute, k, r0, r1, c->band_rows, c->band_rows, ceil_div(r1 - r0, c->band_rows), 0,
+                            !last, done) != LBM_SUCCESS)
               return LBM_FAILURE;
           } else if (!halo) {
             if (launch_step(c, s, sl.compute, 0, 1, sl.rows, 0, !last) != LBM_SUCCESS) return LBM_FAILURE;
@@ -672,10 +757,10 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
           }
           static const int ext_events_b = env_int("LBM_EXT_EVENTS", 1);
           hipEvent_t bdone = ext_events_b ? sl.ev_boundary : nullptr;  // B(m) done
-          if (two) {
-            // rows 0,1 and rows-2,rows-1 as two 2-row bands in one launch
-            const int off = c->n_strips * ceil_div(sl.rows - 4, c->band_rows);
-            if (launch_step2(c, s, sl.comm, 0, sl.rows, 2, sl.rows - 2, 2, off, !last, bdone) != LBM_SUCCESS) return LBM_FAILURE;
+          if (k) {
+            // rows [0, k) and [rows-k, rows) as two k-row bands in one launch
+            const int off = c->n_strips * ceil_div(sl.rows - 2 * k, c->band_rows);
+            if (launch_pass(c, s, sl.comm, k, 0, sl.rows, k, sl.rows - k, 2, off, !last, bdone) != LBM_SUCCESS) return LBM_FAILURE;
           } else {
             if (launch_step(c, s, sl.comm, 0, sl.rows - 1, 2, sl.blocks_main, !last, bdone) != LBM_SUCCESS) return LBM_FAILURE;
           }
@@ -686,18 +771,18 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
     // bookkeeping of the partial slots written by this macro step
     for (int s = 0; s < c->n_slabs; s++) {
       Slab& sl = c->slab[s];
-      const int fused_waves = halo ? c->n_strips * (ceil_div(sl.rows - 4, c->band_rows) + 2)
+      const int fused_waves = halo ? c->n_strips * (ceil_div(sl.rows - 2 * k, c->band_rows) + 2)
                                    : c->n_strips * ceil_div(sl.rows, c->band_rows);
       const int n_part = tile ? tile_count(c)
-                              : (two ? fused_waves : sl.blocks_main + sl.blocks_boundary);
-      for (int k = 0; k < adv; k++) sl.slot_counts.n[c->slot_fill + k] = n_part;
+                              : (k ? fused_waves : sl.blocks_main + sl.blocks_boundary);
+      for (int j = 0; j < adv; j++) sl.slot_counts.n[c->slot_fill + j] = n_part;
     }
     c->cur ^= 1;
     c->slot_fill += adv;
     t += adv;
     // phase 3: the next exchange
     if (halo && !last && exchange_halos(c, depth, c->cur, c->cur, -1) != LBM_SUCCESS) return LBM_FAILURE;
-    if (c->slot_fill + (c->tile_steps > 2 ? c->tile_steps : 2) > kPartSlots || last) {
+    if (c->slot_fill + slots_per_pass > kPartSlots || last) {
       if (flush_partials(c, flushed_upto) != LBM_SUCCESS) return LBM_FAILURE;
       flushed_upto += c->slot_fill;
       c->slot_fill = 0;
@@ -828,8 +913,8 @@ bool validate_params(const lbm_params* p) {
   return p && p->nx >= 1 && p->ny >= 2 && p->max_iters >= 0 && (long)p->nx * (long)p->ny <= 2147483647L;
 }
 
-// Build one slab: allocate, upload mask rows, fill the lattice.
-int build_slab(lbm_ctx* c, int s, const int* obstacles, const float* cells_aos) {
+// Build one slab: allocate, build the mask on the device, fill the lattice.
+int build_slab(lbm_ctx* c, int s, const ObstacleSource& obst, const float* cells_aos) {
   Slab& sl = c->slab[s];
   const lbm_params& p = c->p;
   HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
@@ -860,20 +945,64 @@ int build_slab(lbm_ctx* c, int s, const int* obstacles, const float* cells_aos) 
   HIP_TRY(LBM_FAILURE, hipMalloc(&sl.scratch, 2 * kSumBlocks * sizeof(double)));
   HIP_TRY(LBM_FAILURE, hipMalloc(&sl.flushed_dev, sizeof(int)));
 
-  // obstacle mask: int (reference host type, SerialCode/d2q9-bgk.c:541) -> uint8 (rows+2) x pitch,
-  // with the (periodic) neighbour rows -1 and `rows` so that a slab can relax its halo rows
+  // obstacle mask: uint8 (rows + 2*kMaskHalo) x pitch with the (periodic) neighbour rows beyond the slab, which a
+  // multi-step pass relaxes redundantly.  Built on the device: from the reference's host type (int, SerialCode/
+  // d2q9-bgk.c:541) uploaded row range by row range through a bounded staging buffer, or expanded from a small tile.
   {
-    const long mask_cells = (long)(sl.rows + 2) * c->pitch;
-    std::vector<unsigned char> m((size_t)mask_cells, 0);
-    for (int r = -1; r <= sl.rows; r++) {
-      const int g = ((sl.row_first + r) % p.ny + p.ny) % p.ny;
-      const int* src = obstacles + (size_t)g * p.nx;
-      unsigned char* dst = m.data() + (size_t)(r + 1) * c->pitch;
-      for (int x = 0; x < p.nx; x++) dst[x] = src[x] ? 1 : 0;
-    }
+    const int mrows = sl.rows + 2 * kMaskHalo;
+    const long mask_cells = (long)mrows * c->pitch;
     HIP_TRY(LBM_FAILURE, hipMalloc(&sl.mask_alloc, (size_t)mask_cells));
-    HIP_TRY(LBM_FAILURE, hipMemcpy(sl.mask_alloc, m.data(), (size_t)mask_cells, hipMemcpyHostToDevice));
-    sl.mask = sl.mask_alloc + c->pitch;
+    HIP_TRY(LBM_FAILURE, hipMemsetAsync(sl.mask_alloc, 0, (size_t)mask_cells, sl.compute));
+    sl.mask = sl.mask_alloc + (size_t)kMaskHalo * c->pitch;
+    if (obst.kind == OBST_TILE) {
+      const size_t tn = (size_t)obst.tile_nx * obst.tile_ny;
+      std::vector<unsigned char> t8(tn);
+      for (size_t i = 0; i < tn; i++) t8[i] = obst.data[i] ? 1 : 0;
+      unsigned char* tile_dev = nullptr;
+      HIP_TRY(LBM_FAILURE, hipMalloc(&tile_dev, tn));
+      HIP_TRY(LBM_FAILURE, hipMemcpyAsync(tile_dev, t8.data(), tn, hipMemcpyHostToDevice, sl.compute));
+      hipLaunchKernelGGL(lbm::mask_from_tile, dim3(ceil_div((long)p.nx * mrows, 256)), dim3(256), 0, sl.compute, tile_dev,
+                         obst.tile_nx, obst.tile_ny, sl.mask_alloc, p.nx, c->pitch, sl.row_first - kMaskHalo, mrows, p.ny);
+      HIP_TRY(LBM_FAILURE, hipGetLastError());
+      HIP_TRY(LBM_FAILURE, hipStreamSynchronize(sl.compute));
+      HIP_TRY(LBM_FAILURE, hipFree(tile_dev));
+    } else {
+      long chunk_rows = (32L << 20) / ((long)p.nx * sizeof(int));
+      if (chunk_rows < 1) chunk_rows = 1;
+      int* stage = nullptr;
+      HIP_TRY(LBM_FAILURE, hipMalloc(&stage, (size_t)chunk_rows * p.nx * sizeof(int)));
+      for (int r = 0; r < mrows;) {
+        // source row of mask row r, and how many rows from there are contiguous in the source
+        long src_row;
+        int run = mrows - r;
+        if (obst.kind == OBST_ROWS) {
+          src_row = (long)(sl.row_first - c->row_first) + r;  // the caller's array starts kMaskHalo rows below its first row
+        } else {
+          const int g = ((sl.row_first - kMaskHalo + r) % p.ny + p.ny) % p.ny;
+          src_row = g;
+          if (run > p.ny - g) run = p.ny - g;
+        }
+        if (run > chunk_rows) run = (int)chunk_rows;
+        HIP_TRY(LBM_FAILURE, hipMemcpyAsync(stage, obst.data + (size_t)src_row * p.nx, (size_t)run * p.nx * sizeof(int),
+                                            hipMemcpyHostToDevice, sl.compute));
+        hipLaunchKernelGGL(lbm::mask_from_int, dim3(ceil_div((long)p.nx * run, 256)), dim3(256), 0, sl.compute, stage,
+                           sl.mask_alloc + (size_t)r * c->pitch, p.nx, c->pitch, run);
+        HIP_TRY(LBM_FAILURE, hipGetLastError());
+        HIP_TRY(LBM_FAILURE, hipStreamSynchronize(sl.compute));  // the staging buffer is reused
+        r += run;
+      }
+      HIP_TRY(LBM_FAILURE, hipFree(stage));
+    }
+    // fluid cells of the owned rows (the reference counts them while parsing, MPI_Waitall/d2q9-bgk.c:794-804)
+    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(sl.scratch);
+    HIP_TRY(LBM_FAILURE, hipMemsetAsync(cnt, 0, sizeof(unsigned long long), sl.compute));
+    hipLaunchKernelGGL(lbm::count_blocked, dim3(ceil_div((long)c->pitch * sl.rows, 256 * 16)), dim3(256), 0, sl.compute,
+                       sl.mask, (long)c->pitch * sl.rows, cnt);
+    HIP_TRY(LBM_FAILURE, hipGetLastError());
+    unsigned long long blocked = 0;
+    HIP_TRY(LBM_FAILURE, hipMemcpyAsync(&blocked, cnt, sizeof(blocked), hipMemcpyDeviceToHost, sl.compute));
+    HIP_TRY(LBM_FAILURE, hipStreamSynchronize(sl.compute));
+    sl.fluid_cells = (long)p.nx * sl.rows - (long)blocked;
   }
 
   // lattice: equilibrium or the caller's cells
@@ -894,7 +1023,7 @@ int build_slab(lbm_ctx* c, int s, const int* obstacles, const float* cells_aos) 
     for (int r0 = 0; r0 < sl.rows; r0 += chunk_rows) {
       const int nr = (sl.rows - r0 < chunk_rows) ? sl.rows - r0 : chunk_rows;
       const size_t n = (size_t)nr * p.nx * lbm::kQ;
-      HIP_TRY(LBM_FAILURE, hipMemcpyAsync(stage, cells_aos + (size_t)(sl.row_first + r0) * p.nx * lbm::kQ,
+      HIP_TRY(LBM_FAILURE, hipMemcpyAsync(stage, cells_aos + (size_t)(sl.row_first - (obst.local_cells ? c->row_first : 0) + r0) * p.nx * lbm::kQ,
                                           n * sizeof(float), hipMemcpyHostToDevice, sl.compute));
       hipLaunchKernelGGL(lbm::aos_to_soa, dim3(ceil_div((long)n, 256)), dim3(256), 0, sl.compute, stage,
                          sl.lat[0], c->plane_stride, c->row_pitch, p.nx, r0, nr);
@@ -907,17 +1036,13 @@ int build_slab(lbm_ctx* c, int s, const int* obstacles, const float* cells_aos) 
   return LBM_SUCCESS;
 }
 
-int count_fluid(const lbm_params* p, const int* obstacles) {
-  long n = (long)p->nx * p->ny, fluid = 0;
-  for (long i = 0; i < n; i++) fluid += obstacles[i] ? 0 : 1;
-  return (int)fluid;
-}
-
-lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const float* cells_aos,
+lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, const float* cells_aos,
                        int n_slabs, int math_mode, int rank, int world, const void* unique_id,
                        int device) {
   if (!validate_params(params)) LBM_FAIL(nullptr, "lbm_create: invalid parameters");
-  if (!obstacles) LBM_FAIL(nullptr, "lbm_create: obstacles is NULL");
+  if (!obst.data) LBM_FAIL(nullptr, "lbm_create: obstacles is NULL");
+  if (obst.kind == OBST_TILE && (obst.tile_nx < 1 || obst.tile_ny < 1))
+    LBM_FAIL(nullptr, "lbm_create: invalid obstacle tile %dx%d", obst.tile_nx, obst.tile_ny);
   if (math_mode != LBM_MATH_EXACT && math_mode != LBM_MATH_FAST)
     LBM_FAIL(nullptr, "lbm_create: unknown math mode %d", math_mode);
   if (n_slabs < 1 || n_slabs > kMaxSlabs) LBM_FAIL(nullptr, "lbm_create: n_gpus must be 1..%d", kMaxSlabs);
@@ -931,7 +1056,6 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
   c->rank = rank;
   c->world = world;
   c->capacity = params->max_iters;
-  c->fluid_cells = count_fluid(params, obstacles);
   c->pitch = (int)round_up(params->nx, 64);
   c->plane_stride = c->pitch + env_int("LBM_PLANE_PAD_FLOATS", 0) / 4 * 4;
   c->row_pitch = 9 * c->plane_stride;
@@ -988,14 +1112,17 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
     sl.row_first = c->row_first + first;
     sl.rows = count;
     const int lid = params->ny - 2;  // SerialCode/d2q9-bgk.c:223
-    // slab-local index of the lid row; with several slabs it may be one of MY halo rows (-1 or
-    // rows), which the two-step kernel relaxes redundantly and must accelerate like its owner does
-    sl.accel_row = lbm::kNoRow;
+    // slab-local index of the lid row; with several slabs it may be one of MY halo rows (-kMaskHalo..-1 or
+    // rows..rows+kMaskHalo-1), which a multi-step pass relaxes redundantly and must accelerate like its owner does
+    sl.accel_row = sl.accel_row2 = lbm::kNoRow;
     for (int shift = -1; shift <= 1; shift++) {
       const int local = lid + shift * params->ny - sl.row_first;
       const bool owned = (local >= 0 && local < sl.rows);
-      const bool in_halo = (c->halo != HALO_SELF) && (local == -1 || local == sl.rows);
-      if (owned || in_halo) sl.accel_row = local;
+      const bool in_halo = (c->halo != HALO_SELF) && ((local < 0 && local >= -kMaskHalo) || (local >= sl.rows && local < sl.rows + kMaskHalo));
+      if (owned || in_halo) {
+        if (sl.accel_row == lbm::kNoRow || owned) { if (sl.accel_row != lbm::kNoRow) sl.accel_row2 = sl.accel_row; sl.accel_row = local; }
+        else sl.accel_row2 = local;
+      }
     }
     if (c->halo == HALO_SELF) {
       sl.blocks_main = blocks_for_rows(c, sl.rows);
@@ -1033,6 +1160,13 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
   c->fuse2 = (c->vec4 && env_int("LBM_FUSE2", (min_cells >= 560L * 1024 || halo_on) ? 1 : 0)) ? 1 : 0;
   c->lane_cells = env_int("LBM_LANE_CELLS", min_cells >= 6L * 1024 * 1024 ? 4 : 2) == 2 ? 2 : 4;
   c->n_strips = ceil_div(params->nx / c->lane_cells > 0 ? params->nx / c->lane_cells : 1, lbm::kStripQuads);
+  // timesteps per pass of the stream kernel (3 needs the 4-cell form), its prefetch and XCD-chunk flavours
+  c->pass_steps = env_int("LBM_PASS_STEPS", 2);
+  if (c->pass_steps < 2 || c->pass_steps > 3 || c->lane_cells != 4) c->pass_steps = 2;
+  c->prefetch = env_int("LBM_PREFETCH", 0) ? 1 : 0;
+  c->xcd_chunk = env_int("LBM_XCD_CHUNK", 0);
+  if (c->xcd_chunk < 0 || c->xcd_chunk > c->n_strips) c->xcd_chunk = 0;
+  c->use_stepk = env_int("LBM_STEPK", 0) ? 1 : 0;
   // Band height.  A wave sweeps band_rows + 2 rows.
   //   4-cell form (256 CUs x 12 waves resident): short bands, by row width -- measured optimum 7 rows at 8192 cells
   //   per row (8192^2: 0.477-0.480 ms vs 0.481-0.484 at 6, 0.495 at 4; same in the halo pipeline), 4-5 rows for
@@ -1062,11 +1196,14 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
   }
   if (c->band_rows < 1) c->band_rows = 1;
   for (int s = 0; s < n_slabs; s++) {
-    // across slabs the two-step kernel needs slabs of at least 4 rows
+    // across slabs a K-step pass needs slabs of at least 2K rows; a periodic slab at least K
+    if (c->halo != HALO_SELF && c->slab[s].rows < 2 * c->pass_steps) c->pass_steps = 2;
     if (c->halo != HALO_SELF && c->slab[s].rows < 4) c->fuse2 = 0;
+    if (c->slab[s].rows < c->pass_steps) c->pass_steps = 2;
     const int waves = c->n_strips * (ceil_div(c->slab[s].rows, c->band_rows) + 2);
     if (c->fuse2 && waves > max_blocks) max_blocks = waves;
   }
+  if (world > 1 && params->ny / world < 2 * c->pass_steps) c->pass_steps = 2;
   if (world > 1 && params->ny / world < 4) c->fuse2 = 0;
   // LDS-tile kernel (several timesteps per launch) for small single-slab grids: LBM_TILE_STEPS overrides
   if (!halo_on) {
@@ -1090,7 +1227,7 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
   c->part_stride = round_up(max_blocks, 64);
 
   for (int s = 0; s < n_slabs; s++)
-    if (build_slab(c, s, obstacles, cells_aos) != LBM_SUCCESS) {
+    if (build_slab(c, s, obst, cells_aos) != LBM_SUCCESS) {
       lbm_destroy(c);
       return nullptr;
     }
@@ -1115,6 +1252,26 @@ lbm_ctx* create_common(const lbm_params* params, const int* obstacles, const flo
       return nullptr;
     }
     for (int s = 0; s < n_slabs; s++) c->slab[s].nccl = comms[s];
+  }
+  // global number of fluid cells (av_velocity's divisor): the slabs' device-side counts, summed over the ranks
+  // (the reference counts on rank 0 while parsing, MPI_Waitall/d2q9-bgk.c:794-804)
+  {
+    long long fluid = 0;
+    for (int s = 0; s < n_slabs; s++) fluid += c->slab[s].fluid_cells;
+    if (c->ranked && world > 1) {
+      Slab& sl = c->slab[0];
+      long long* dev = reinterpret_cast<long long*>(sl.scratch);
+      if (hipSetDevice(sl.device) != hipSuccess ||
+          hipMemcpy(dev, &fluid, sizeof(fluid), hipMemcpyHostToDevice) != hipSuccess ||
+          ncclAllReduce(dev, dev, 1, ncclInt64, ncclSum, sl.nccl, sl.comm) != ncclSuccess ||
+          hipStreamSynchronize(sl.comm) != hipSuccess ||
+          hipMemcpy(&fluid, dev, sizeof(fluid), hipMemcpyDeviceToHost) != hipSuccess) {
+        raise_error(__LINE__, "lbm_create_rank: all-reduce of the fluid-cell count failed");
+        lbm_destroy(c);
+        return nullptr;
+      }
+    }
+    c->fluid_cells = (int)fluid;
   }
   // one issuing thread per slab when one process drives several slabs: opt-in (LBM_THREADS=1).
   // With several slabs on ONE device it is slower (the runtime serialises calls to a device:
@@ -1159,7 +1316,14 @@ int lbm_partition_rows(int ny, int parts, int index, int* first, int* count) {
 
 lbm_ctx* lbm_create(const lbm_params* params, const int* obstacles, const float* cells_aos,
                     int n_gpus, int math_mode) {
-  return create_common(params, obstacles, cells_aos, n_gpus, math_mode, 0, 1, nullptr, 0);
+  const ObstacleSource obst = {OBST_GLOBAL, obstacles, 0, 0, false};
+  return create_common(params, obst, cells_aos, n_gpus, math_mode, 0, 1, nullptr, 0);
+}
+
+lbm_ctx* lbm_create_tiled(const lbm_params* params, const int* tile, int tile_nx, int tile_ny,
+                          const float* cells_aos, int n_gpus, int math_mode) {
+  const ObstacleSource obst = {OBST_TILE, tile, tile_nx, tile_ny, false};
+  return create_common(params, obst, cells_aos, n_gpus, math_mode, 0, 1, nullptr, 0);
 }
 
 int lbm_rccl_unique_id(void* id_out) {
@@ -1171,11 +1335,37 @@ int lbm_rccl_unique_id(void* id_out) {
   return LBM_SUCCESS;
 }
 
+static bool rank_args_ok(int rank, int world_size, const void* unique_id) {
+  if (world_size < 1 || rank < 0 || rank >= world_size) {
+    raise_error(__LINE__, "lbm_create_rank: bad rank %d of %d", rank, world_size);
+    return false;
+  }
+  if (!unique_id) {
+    raise_error(__LINE__, "lbm_create_rank: unique_id is NULL");
+    return false;
+  }
+  return true;
+}
+
 lbm_ctx* lbm_create_rank(const lbm_params* params, const int* obstacles, const float* cells_aos,
                          int rank, int world_size, const void* unique_id, int device, int math_mode) {
-  if (world_size < 1 || rank < 0 || rank >= world_size) LBM_FAIL(nullptr, "lbm_create_rank: bad rank %d of %d", rank, world_size);
-  if (!unique_id) LBM_FAIL(nullptr, "lbm_create_rank: unique_id is NULL");
-  return create_common(params, obstacles, cells_aos, 1, math_mode, rank, world_size, unique_id, device);
+  if (!rank_args_ok(rank, world_size, unique_id)) return nullptr;
+  const ObstacleSource obst = {OBST_GLOBAL, obstacles, 0, 0, false};
+  return create_common(params, obst, cells_aos, 1, math_mode, rank, world_size, unique_id, device);
+}
+
+lbm_ctx* lbm_create_rank_rows(const lbm_params* params, const int* obstacle_rows, const float* cells_rows_aos,
+                              int rank, int world_size, const void* unique_id, int device, int math_mode) {
+  if (!rank_args_ok(rank, world_size, unique_id)) return nullptr;
+  const ObstacleSource obst = {OBST_ROWS, obstacle_rows, 0, 0, true};
+  return create_common(params, obst, cells_rows_aos, 1, math_mode, rank, world_size, unique_id, device);
+}
+
+lbm_ctx* lbm_create_rank_tiled(const lbm_params* params, const int* tile, int tile_nx, int tile_ny,
+                               int rank, int world_size, const void* unique_id, int device, int math_mode) {
+  if (!rank_args_ok(rank, world_size, unique_id)) return nullptr;
+  const ObstacleSource obst = {OBST_TILE, tile, tile_nx, tile_ny, false};
+  return create_common(params, obst, nullptr, 1, math_mode, rank, world_size, unique_id, device);
 }
 
 void lbm_destroy(lbm_ctx* c) {
@@ -1207,8 +1397,13 @@ int lbm_get_info(const lbm_ctx* c, lbm_info* out) {
   out->world_rank = c->rank;
   out->world_size = c->world;
   const bool stale = (c->halo != HALO_SELF && c->halo_mode == LBM_HALO_STALE);
-  out->steps_per_launch = (c->tile_steps && c->halo == HALO_SELF) ? c->tile_steps : ((c->fuse2 && !stale) ? 2 : 1);
+  out->steps_per_launch = (c->tile_steps && c->halo == HALO_SELF) ? c->tile_steps : ((c->fuse2 && !stale) ? c->pass_steps : 1);
   out->halo_mode = c->halo_mode;
+  const bool stream_kernel = c->fuse2 && !stale && !(c->tile_steps && c->halo == HALO_SELF);
+  out->band_rows = stream_kernel ? c->band_rows : 0;
+  out->lane_cells = stream_kernel ? c->lane_cells : 0;
+  out->nontemporal = c->nts;
+  out->graph_steps = (c->use_graph && c->halo == HALO_SELF) ? kPartSlots : 0;
   return LBM_SUCCESS;
 }
 

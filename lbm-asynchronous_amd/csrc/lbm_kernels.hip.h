@@ -207,23 +207,43 @@ __device__ __forceinline__ void moments_shared(const float (&f)[kQ], float& rho,
   }
 }
 
-template <>
-__device__ __forceinline__ void collide<true>(const float (&t)[kQ], float omega, float (&r)[kQ],
+// SPEED: where |u| for the av_velocity sum comes from
+//   0  the relaxed populations, IEEE sqrt -- the reference's own arithmetic (SerialCode/d2q9-bgk.c:426-450):
+//      per-cell |u| bit-identical to the reference's
+//   1  the pre-collision moments (BGK conserves density and momentum, so they equal the relaxed cell's up to
+//      rounding, ~1e-7 relative), native v_sqrt_f32 (1 ulp): saves the second moment pass, ~50 VALU
+//      instructions per cell.  The lattice is untouched by this choice; av_vels moves by < 1e-6 relative,
+//      far inside the summation-order noise it already carries (the reference adds sequentially in fp32).
+#ifndef LBM_STREAM_SPEED
+#define LBM_STREAM_SPEED 1
+#endif
+template <int SPEED = 0>
+__device__ __forceinline__ void collide_exact(const float (&t)[kQ], float omega, float (&r)[kQ],
                                               float& speed, bool want_speed) {
   float rho, ux, uy;
   moments_shared(t, rho, ux, uy);
   // |u|^2 below 5e28 bounds every dividend of the fast constant divides (squares of ux, uy,
   // ux+-uy are at most 2|u|^2 < 1e29); NaN compares false and takes the IEEE path
-  const bool ok = (ux * ux + uy * uy) < 5.0e28f;
+  const float u_sq = ux * ux + uy * uy;
+  const bool ok = u_sq < 5.0e28f;
   if (ok) collide_exact_body<true>(t, omega, rho, ux, uy, r);
   else    collide_exact_body<false>(t, omega, rho, ux, uy, r);
-  // av_velocity() looks at the relaxed populations (SerialCode/d2q9-bgk.c:169, 426-450)
   speed = 0.f;
   if (want_speed) {
-    float rho2, ux2, uy2;
-    moments_shared(r, rho2, ux2, uy2);
-    speed = sqrtf((ux2 * ux2) + (uy2 * uy2));  // IEEE: __fsqrt_rn is the native approximation
+    if constexpr (SPEED == 0) {
+      // av_velocity() looks at the relaxed populations (SerialCode/d2q9-bgk.c:169, 426-450)
+      float rho2, ux2, uy2;
+      moments_shared(r, rho2, ux2, uy2);
+      speed = sqrtf((ux2 * ux2) + (uy2 * uy2));  // IEEE: __fsqrt_rn is the native approximation
+    } else {
+      speed = __builtin_amdgcn_sqrtf(u_sq);
+    }
   }
+}
+template <>
+__device__ __forceinline__ void collide<true>(const float (&t)[kQ], float omega, float (&r)[kQ],
+                                              float& speed, bool want_speed) {
+  collide_exact<0>(t, omega, r, speed, want_speed);
 }
 
 // FAST: one reciprocal, multiplies by 3, 4.5, 1.5 and explicit FMAs.  BGK conserves density and
@@ -488,18 +508,19 @@ struct Step2Args {
   float omega, a1, a2;
   float* partials1;  // per wave: sum |u| after step t   (own cells only)
   float* partials2;  // per wave: sum |u| after step t+1
+  int stagger;       // start delay per resident-wave slot, in units of s_sleep 127 (~8128 clocks); 0 = none
 };
 
 constexpr int kStripQuads = 62;  // output lanes per wave (lanes 1..62; each owns C cells)
 
-template <int MATH>
+template <int MATH, int SPEED = 0>
 __device__ __forceinline__ void relax_cell(const float (&t)[kQ], bool blocked, bool lid, float omega, float a1,
                                            float a2, float (&r)[kQ], float& speed, bool want_speed = true) {
   speed = 0.f;
   if (blocked) {
     bounce(t, r);
   } else {
-    if constexpr (MATH == 0) collide<true>(t, omega, r, speed, want_speed);
+    if constexpr (MATH == 0) collide_exact<SPEED>(t, omega, r, speed, want_speed);
     else collide<false>(t, omega, r, speed, want_speed);
     if (lid) accelerate(r, a1, a2);
   }
@@ -556,6 +577,12 @@ __global__ __launch_bounds__(64) void step2_stream(const Step2Args a) {
   const int lane = threadIdx.x;
   const int strip = blockIdx.x % a.n_strips;
   const int units_x = a.nx / C;
+  if (a.stagger) {
+    // waves that share a SIMD and start together stay in lockstep (all wait for their loads, then all
+    // compute): offset them by their slot on the SIMD so that one computes while the others wait
+    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_ID.wave_id
+    for (unsigned i = 0; i < (slot % 3u) * (unsigned)a.stagger; i++) __builtin_amdgcn_s_sleep(127);
+  }
   const int y0 = a.row_first + (int)(blockIdx.x / a.n_strips) * a.band_pitch;
   const int band_n = min(a.band_rows, a.row_end - y0);
 
@@ -607,7 +634,7 @@ __global__ __launch_bounds__(64) void step2_stream(const Step2Args a) {
 #pragma unroll
     for (int j = 0; j < C; j++) {
       float speed;
-      relax_cell<MATH>(t[j], ((p.m >> (8 * j)) & 0xffu) != 0, lid, a.omega, a.a1, a.a2, N[j], speed, own_row);
+      relax_cell<MATH, LBM_STREAM_SPEED>(t[j], ((p.m >> (8 * j)) & 0xffu) != 0, lid, a.omega, a.a1, a.a2, N[j], speed, own_row);
       if (own_row && out_lane) sum1 += speed;
     }
 
@@ -640,7 +667,7 @@ __global__ __launch_bounds__(64) void step2_stream(const Step2Args a) {
 #pragma unroll
       for (int j = 0; j < C; j++) {
         float speed;
-        relax_cell<MATH>(u[j], ((m_prev >> (8 * j)) & 0xffu) != 0, lid2, a.omega, a.a1, a.a2, R[j], speed);
+        relax_cell<MATH, LBM_STREAM_SPEED>(u[j], ((m_prev >> (8 * j)) & 0xffu) != 0, lid2, a.omega, a.a1, a.a2, R[j], speed);
         if (out_lane) sum2 += speed;
       }
       if (out_lane) {
@@ -671,6 +698,223 @@ __global__ __launch_bounds__(64) void step2_stream(const Step2Args a) {
   if (lane == 0) {
     a.partials1[blockIdx.x] = sum1;
     a.partials2[blockIdx.x] = sum2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K timesteps per pass over memory (K = 2, 3 or 4): the sliding register window of step2_stream generalised
+// to a chain of K-1 windows.  The two-step kernel at 8192^2 is bound by DRAM traffic (round-2 PMC: 5.4-5.8 TB/s
+// at the memory controllers whatever the band height and however cheap the arithmetic), so the only way
+// on is fewer bytes per update: K = 3 reads and writes the lattice once per THREE updates (24 B per update).
+//
+// Iteration i of a wave pulls row r = y0 - (K-1) + i and relaxes it (stage 1); stage s+1 then relaxes row
+// r - s from window s (speeds 2,5,6 of row r-s-1, speeds 0,1,3 of row r-s) and the stage-s results of row
+// r-s+1 just produced (speeds 4,7,8), +-1 columns by DPP from the adjacent lanes; the last stage's row
+// r - (K-1) is stored.  Every intermediate value is consumed exactly once: 36 floats per window and lane.
+// Redundant work: 2 of 64 lanes (with 4 cells per lane one halo lane per side covers up to four steps: after
+// stage s the s cells of a halo lane nearest the strip's edge are garbage, and stage s+1 of the first owned
+// cell needs the halo lane's LAST cell of stage s) and 2(K-1) warm-up rows per band in stage 1, 2(K-2) in
+// stage 2, ...  Per-cell arithmetic is relax_cell, as in every other kernel: the lattice stays bit-identical.
+//
+// PREFETCH: the next row's nine vectors are requested before the current row is relaxed (36 more VGPRs; with
+// two resident waves per SIMD the loads of one wave would otherwise only overlap the other wave's arithmetic
+// when the two happen to be out of phase).
+// XCD: workgroups are handed to the 8 XCDs round-robin; with chunk > 0, consecutive workgroups OF ONE XCD take
+// horizontally adjacent strips of one band (a chunk), so the 128-byte lines that straddle two strips
+// (a strip is 62 x 16 B = 992 B wide) are fetched from the fabric once per chunk instead of once per strip.
+// ---------------------------------------------------------------------------------------------
+struct StepKArgs {
+  const float* src;
+  float* dst;
+  const unsigned char* mask;
+  long plane_stride;
+  long row_pitch;
+  int pitch;
+  int nx;
+  int rows;        // rows owned by the slab
+  int wrap;        // 1: rows wrap periodically (single slab); 0: K halo rows surround the slab
+  int band_rows;   // output rows per wave (band height)
+  int row_first;   // band b of this launch starts at row_first + b*band_pitch ...
+  int band_pitch;  // (= band_rows for a contiguous region)
+  int row_end;     // ... and ends before row_end
+  int n_strips;    // waves across x
+  int n_bands;     // bands of this launch
+  int chunk;       // strips per XCD chunk (0: plain order, strip fastest)
+  int accel_row;
+  int accel_row2;  // a second periodic image of the lid row among the halo rows, or kNoRow
+  int accel_after;
+  float omega, a1, a2;
+  float* partials;      // partials[s * slot_stride + wave] = sum |u| after step t+s (own cells only)
+  long slot_stride;
+};
+
+template <int C>
+struct Window {
+  float w256[3][C];  // speeds 2,5,6 of the row two below the newest
+  float w013[3][C];  // speeds 0,1,3 of the row below the newest
+  float n256[3][C];  // speeds 2,5,6 of the row below the newest (become w256 after the rotation)
+  unsigned m;        // mask bytes of the row below the newest
+};
+
+template <int MATH, bool NTS, int C, int K, bool PREFETCH>
+__global__ __launch_bounds__(64, (K >= 3 || PREFETCH) ? 2 : 3) void stepk_stream(const StepKArgs a) {
+  static_assert(K >= 2 && K <= 4 && (C == 4 || K == 2), "one halo lane per side covers K <= C steps");
+  typedef typename RowPull<C>::vec vec;
+  const int lane = threadIdx.x;
+  int strip, band;
+  if (a.chunk > 0) {
+    // workgroup w runs on XCD w % 8 as that XCD's (w / 8)-th workgroup; chunk g = (strips [h*chunk, (h+1)*chunk) of band b)
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int chunks_per_band = (a.n_strips + a.chunk - 1) / a.chunk;
+    const int g = (j / a.chunk) * 8 + xcd;
+    band = g / chunks_per_band;
+    strip = (g - band * chunks_per_band) * a.chunk + j % a.chunk;
+    if (band >= a.n_bands || strip >= a.n_strips) return;
+  } else {
+    strip = blockIdx.x % a.n_strips;
+    band = blockIdx.x / a.n_strips;
+  }
+  const int wave_id = band * a.n_strips + strip;
+  const int units_x = a.nx / C;
+  const int y0 = a.row_first + band * a.band_pitch;
+  const int band_n = min(a.band_rows, a.row_end - y0);
+
+  const int ux_raw = strip * kStripQuads + lane - 1;
+  int ux = ux_raw % units_x;
+  if (ux < 0) ux += units_x;
+  const int x0 = ux * C;
+  const bool out_lane = (lane >= 1) && (lane <= kStripQuads) && (ux_raw < units_x);
+  const long ps = a.plane_stride;
+
+  Step2Args pa;  // pull_row's view of the arguments
+  pa.src = a.src;  pa.mask = a.mask;  pa.plane_stride = a.plane_stride;  pa.row_pitch = a.row_pitch;
+  pa.pitch = a.pitch;  pa.rows = a.rows;  pa.wrap = a.wrap;
+
+  Window<C> win[K - 1];
+#pragma unroll
+  for (int s = 0; s < K - 1; s++) {
+    win[s].m = 0;
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+      for (int j = 0; j < C; j++) win[s].w256[q][j] = win[s].w013[q][j] = win[s].n256[q][j] = 0.f;
+  }
+  float sum[K];
+#pragma unroll
+  for (int s = 0; s < K; s++) sum[s] = 0.f;
+
+  const int n_iter = band_n + 2 * (K - 1);
+  RowPull<C> nextp;
+  if constexpr (PREFETCH) nextp = pull_row<C>(pa, wrap_row(y0 - (K - 1), a.rows, a.wrap), x0);
+
+  for (int i = 0; i < n_iter; i++) {
+    // ---- stage 1: step t on row r, pulled from memory -------------------------------------------
+    const int r = wrap_row(y0 - (K - 1) + i, a.rows, a.wrap);
+    RowPull<C> p;
+    if constexpr (PREFETCH) {
+      p = nextp;
+      if (i + 1 < n_iter) nextp = pull_row<C>(pa, wrap_row(y0 - (K - 1) + i + 1, a.rows, a.wrap), x0);
+    } else {
+      p = pull_row<C>(pa, r, x0);
+    }
+    float cur[C][kQ];
+    {
+      const float e1 = lane_from_west<2>(p.v[1][C - 1]), e5 = lane_from_west<2>(p.v[5][C - 1]),
+                  e8 = lane_from_west<2>(p.v[8][C - 1]);
+      const float e3 = lane_from_east<2>(p.v[3][0]), e6 = lane_from_east<2>(p.v[6][0]),
+                  e7 = lane_from_east<2>(p.v[7][0]);
+      const bool lid = (r == a.accel_row) || (r == a.accel_row2);
+      const bool own_row = (i >= K - 1) && (i < band_n + K - 1);
+#pragma unroll
+      for (int j = 0; j < C; j++) {
+        const int jw = (j == 0) ? 0 : j - 1, je = (j == C - 1) ? C - 1 : j + 1;
+        const float t[kQ] = {p.v[0][j],
+                             (j == 0) ? e1 : p.v[1][jw],
+                             p.v[2][j],
+                             (j == C - 1) ? e3 : p.v[3][je],
+                             p.v[4][j],
+                             (j == 0) ? e5 : p.v[5][jw],
+                             (j == C - 1) ? e6 : p.v[6][je],
+                             (j == C - 1) ? e7 : p.v[7][je],
+                             (j == 0) ? e8 : p.v[8][jw]};
+        float speed;
+        relax_cell<MATH, LBM_STREAM_SPEED>(t, ((p.m >> (8 * j)) & 0xffu) != 0, lid, a.omega, a.a1, a.a2, cur[j], speed,
+                                           own_row);
+        if (own_row && out_lane) sum[0] += speed;
+      }
+    }
+    unsigned m_cur = p.m;  // mask bytes of the row `cur` belongs to
+
+    // ---- stages 2..K: step t+s on row r-s from window s and the stage-s results of row r-s+1 ----
+#pragma unroll
+    for (int s = 1; s < K; s++) {
+      Window<C>& w = win[s - 1];
+      float nxt[C][kQ];
+      const bool active = (i >= 2 * s);
+      if (active) {
+        const int ro = wrap_row(y0 - (K - 1) + i - s, a.rows, a.wrap);
+        const float w1 = lane_from_west<2>(w.w013[1][C - 1]);
+        const float w5 = lane_from_west<2>(w.w256[1][C - 1]);
+        const float w8 = lane_from_west<2>(cur[C - 1][8]);
+        const float x3 = lane_from_east<2>(w.w013[2][0]);
+        const float x6 = lane_from_east<2>(w.w256[2][0]);
+        const float x7 = lane_from_east<2>(cur[0][7]);
+        const bool last = (s == K - 1);
+        const bool lid = ((ro == a.accel_row) || (ro == a.accel_row2)) && (!last || a.accel_after);
+        // rows of this band: ro in [y0, y0 + band_n)  <=>  i - s - (K-1) in [0, band_n)
+        const bool own_row = (i - s >= K - 1) && (i - s < band_n + K - 1);
+#pragma unroll
+        for (int j = 0; j < C; j++) {
+          const int jw = (j == 0) ? 0 : j - 1, je = (j == C - 1) ? C - 1 : j + 1;
+          const float u[kQ] = {w.w013[0][j],
+                               (j == 0) ? w1 : w.w013[1][jw],
+                               w.w256[0][j],
+                               (j == C - 1) ? x3 : w.w013[2][je],
+                               cur[j][4],
+                               (j == 0) ? w5 : w.w256[1][jw],
+                               (j == C - 1) ? x6 : w.w256[2][je],
+                               (j == C - 1) ? x7 : cur[je][7],
+                               (j == 0) ? w8 : cur[jw][8]};
+          float speed;
+          relax_cell<MATH, LBM_STREAM_SPEED>(u, ((w.m >> (8 * j)) & 0xffu) != 0, lid, a.omega, a.a1, a.a2, nxt[j], speed,
+                                             own_row);
+          if (own_row && out_lane) sum[s] += speed;
+        }
+      }
+      // rotate window s with the stage-s row just consumed
+      const unsigned m_below = w.m;
+#pragma unroll
+      for (int j = 0; j < C; j++) {
+        w.w256[0][j] = w.n256[0][j];  w.w256[1][j] = w.n256[1][j];  w.w256[2][j] = w.n256[2][j];
+        w.n256[0][j] = cur[j][2];     w.n256[1][j] = cur[j][5];     w.n256[2][j] = cur[j][6];
+        w.w013[0][j] = cur[j][0];     w.w013[1][j] = cur[j][1];     w.w013[2][j] = cur[j][3];
+      }
+      w.m = m_cur;
+      if (!active) break;
+      m_cur = m_below;
+#pragma unroll
+      for (int j = 0; j < C; j++)
+#pragma unroll
+        for (int k = 0; k < kQ; k++) cur[j][k] = nxt[j][k];
+      if (s == K - 1 && out_lane) {
+        const int ro = wrap_row(y0 - (K - 1) + i - s, a.rows, a.wrap);
+        float* d_row = a.dst + (long)ro * a.row_pitch + x0;
+#pragma unroll
+        for (int k = 0; k < kQ; k++) {
+          vec o;
+#pragma unroll
+          for (int j = 0; j < C; j++) o[j] = cur[j][k];
+          if constexpr (NTS) __builtin_nontemporal_store(o, reinterpret_cast<vec*>(d_row + k * ps));
+          else *reinterpret_cast<vec*>(d_row + k * ps) = o;
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int s = 0; s < K; s++) {
+    const float tot = wave_sum(sum[s]);
+    if (lane == 0) a.partials[(long)s * a.slot_stride + wave_id] = tot;
   }
 }
 
@@ -874,6 +1118,43 @@ __global__ __launch_bounds__(kBlock) void reduce_partials(const float* partials,
 
 __global__ void set_counter(int* p, int value) { *p = value; }
 __global__ void advance_counter(int* p, int by) { *p += by; }
+
+// obstacle flags: the reference's int map (1 = blocked, SerialCode/d2q9-bgk.c:541, 570-601) -> uint8 rows of `pitch`
+__global__ void mask_from_int(const int* src, unsigned char* dst, int nx, int pitch, int nrows) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)nx * nrows) return;
+  const int r = (int)(i / nx), x = (int)(i - (long)r * nx);
+  dst[(long)r * pitch + x] = src[i] ? 1 : 0;
+}
+
+// ... or a small tile repeated over the grid: cell (x, y) is blocked iff the tile's cell (x mod tnx, y mod tny) is
+// (the synthetic 8192^2 / 16384^2 grids tile the reference's 1024^2 map).  Mask row r is
+// global row row0 + r, folded periodically into [0, ny).
+__global__ void mask_from_tile(const unsigned char* tile, int tnx, int tny, unsigned char* dst, int nx, int pitch,
+                               int row0, int nrows, int ny) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)nx * nrows) return;
+  const int r = (int)(i / nx), x = (int)(i - (long)r * nx);
+  int g = (row0 + r) % ny;
+  if (g < 0) g += ny;
+  dst[(long)r * pitch + x] = tile[(long)(g % tny) * tnx + (x % tnx)];
+}
+
+// number of blocked cells among n mask bytes (pitch padding is zero)
+__global__ __launch_bounds__(256) void count_blocked(const unsigned char* mask, long n, unsigned long long* out) {
+  __shared__ unsigned int sh[256];
+  unsigned int acc = 0;
+  const long base = ((long)blockIdx.x * 256 + threadIdx.x) * 16;
+  for (int k = 0; k < 16; k++)
+    if (base + k < n) acc += mask[base + k] ? 1u : 0u;
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && sh[0]) atomicAdd(out, (unsigned long long)sh[0]);
+}
 
 // uniform equilibrium start (SerialCode/d2q9-bgk.c:546-567)
 __global__ void init_equilibrium(float* lat, long ps, long row_pitch, int nx, int rows, float r0,

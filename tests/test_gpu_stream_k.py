@@ -1,0 +1,133 @@
+"""GPU parity of round 2's additions: the K-timesteps-per-pass stream kernel (stepk_stream: K = 2, 3; next-row
+prefetch; XCD-chunked workgroup order), and the device-side mask construction (global map, per-rank rows,
+periodic tile) with its device-side fluid-cell count.  Everything through the C ABI against the CPU oracle;
+the lattice must stay bit-identical (see test_gpu_parity.py for the av_vels tolerance)."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import AV_RTOL, random_case, run_both
+
+pytestmark = pytest.mark.gpu
+
+
+def force_stream(monkeypatch, k, band, prefetch=0, chunk=0, stepk=1):
+    monkeypatch.setenv("LBM_FUSE2", "1")
+    monkeypatch.setenv("LBM_LANE_CELLS", "4")
+    monkeypatch.setenv("LBM_PASS_STEPS", str(k))
+    monkeypatch.setenv("LBM_BAND_ROWS", str(band))
+    monkeypatch.setenv("LBM_PREFETCH", str(prefetch))
+    monkeypatch.setenv("LBM_XCD_CHUNK", str(chunk))
+    monkeypatch.setenv("LBM_STEPK", str(stepk))
+
+
+@pytest.mark.parametrize("k", [2, 3])
+@pytest.mark.parametrize("band,prefetch,chunk", [(2, 0, 0), (7, 1, 0), (5, 0, 3), (64, 1, 1), (3, 1, 2)])
+@pytest.mark.parametrize("slabs,halo", [(1, None), (1, "rccl"), (2, "memcpy"), (3, "memcpy"), (8, "memcpy")])
+def test_k_steps_per_pass_bitwise(lbm, oracle, datasets, monkeypatch, k, band, prefetch, chunk, slabs, halo):
+    """Reference data set 128x256 (periodic wrap in y live, wall row in the middle); 76 = 25 three-step passes
+    + 1 single step, or 38 two-step passes; 77 ends a three-step run with a two-step pass."""
+    force_stream(monkeypatch, k, band, prefetch, chunk)
+    if halo:
+        monkeypatch.setenv("LBM_HALO", halo)
+        if slabs == 1:
+            monkeypatch.setenv("LBM_FORCE_HALO", "1")
+    p, ob = datasets("128x256")
+    cells = oracle.init_cells(p)
+    for steps in (76, 77):
+        ref_cells, ref_av, got_cells, got_av, fields = run_both(lbm, oracle, p, ob, cells, steps, n_gpus=slabs)
+        assert np.array_equal(ref_cells.view(np.uint32), got_cells.view(np.uint32)), steps
+        np.testing.assert_allclose(got_av, ref_av, rtol=AV_RTOL)
+        ref_f = oracle.final_state(p, ref_cells, ob)
+        assert np.array_equal(ref_f["pressure"].view(np.uint32), fields["pressure"].view(np.uint32))
+
+
+def test_three_step_info_and_pieces(lbm, oracle, datasets, monkeypatch):
+    """lbm_run in pieces of every residue mod 3 with three slabs: each piece starts with its own accelerate
+    pass and exchange and may end with a two-step or a one-step pass."""
+    force_stream(monkeypatch, 3, 4)
+    monkeypatch.setenv("LBM_HALO", "memcpy")
+    p, ob = datasets("128x256")
+    cells = oracle.init_cells(p)
+    ref = cells.copy()
+    ref_av = oracle.run(p, ref, ob, 70)
+    with lbm.Engine(p, ob, cells, n_gpus=3) as eng:
+        info = eng.info()
+        assert info["steps_per_launch"] == 3 and info["band_rows"] == 4 and info["lane_cells"] == 4
+        for n in (1, 2, 3, 4, 5, 7, 48):
+            eng.run(n)
+        assert eng.info()["steps_done"] == 70
+        assert np.array_equal(eng.cells().view(np.uint32), ref.view(np.uint32))
+        np.testing.assert_allclose(eng.av_vels(70), ref_av, rtol=AV_RTOL)
+
+
+def test_three_step_random_lattices(lbm, oracle, monkeypatch):
+    """Random populations / obstacles, both periodic wraps live, several strips per row, uneven slabs, lid row
+    next to a slab edge, slabs just tall enough for a three-step pass (6 rows)."""
+    monkeypatch.setenv("LBM_HALO", "memcpy")
+    for nx, ny, slabs, band, pf, chunk, steps in ((256, 24, 1, 3, 0, 0, 20), (512, 25, 4, 3, 1, 2, 19), (64, 40, 5, 2, 0, 1, 21),
+                                                  (1024, 13, 2, 5, 1, 0, 9), (4096, 67, 3, 8, 1, 4, 10), (2048, 9, 1, 4, 0, 3, 8),
+                                                  (8, 3, 1, 2, 0, 0, 7), (12, 6, 1, 7, 1, 0, 12)):
+        force_stream(monkeypatch, 3, band, pf, chunk)
+        p, ob, cells = random_case(lbm, nx, ny, 300 + ny, walls=False)
+        ref_cells, ref_av, got_cells, got_av, _ = run_both(lbm, oracle, p, ob, cells, steps, n_gpus=slabs)
+        assert np.array_equal(ref_cells.view(np.uint32), got_cells.view(np.uint32)), (nx, ny, slabs)
+        np.testing.assert_allclose(got_av, ref_av, rtol=AV_RTOL)
+
+
+def test_three_step_rank_api_rccl_self(lbm, oracle, datasets, monkeypatch):
+    """The one-process-per-GPU pipeline with three-step passes: 3-row halos through RCCL send/recv to itself."""
+    force_stream(monkeypatch, 3, 5, 1, 0)
+    monkeypatch.setenv("LBM_FORCE_HALO", "1")
+    p, ob = datasets("128x256")
+    cells = oracle.init_cells(p)
+    ref = cells.copy()
+    ref_av = oracle.run(p, ref, ob, 47)
+    with lbm.Engine(p, ob, cells, rank=0, world_size=1, unique_id=lbm.rccl_unique_id(), device=0) as eng:
+        eng.run(47)
+        assert np.array_equal(eng.cells().view(np.uint32), ref.view(np.uint32))
+        np.testing.assert_allclose(eng.av_vels(47), ref_av, rtol=AV_RTOL)
+
+
+# ------------------------------------------------------------------------------------------------
+# mask construction on the device
+# ------------------------------------------------------------------------------------------------
+def test_tiled_obstacles_equal_global_map(lbm, oracle, datasets, monkeypatch):
+    """lbm_create_tiled: the mask expanded on the device from a tile equals the host-tiled global map --
+    same lattice, same fluid-cell count, also across slabs (mask halo rows wrap periodically)."""
+    monkeypatch.setenv("LBM_HALO", "memcpy")
+    _, tile = datasets("128x128")
+    for nx, ny, slabs in ((512, 384, 1), (384, 256, 3), (200, 150, 2)):          # the last one cuts tiles
+        p = lbm.Params(nx, ny, 30, 10, 0.1, 0.005, 1.85)
+        ob = lbm.tile_obstacles(tile, nx, ny)
+        with lbm.Engine(p, ob, None, n_gpus=slabs) as a, lbm.Engine(p, tile, None, n_gpus=slabs, tiled=True) as b:
+            assert a.info()["fluid_cells"] == b.info()["fluid_cells"] == int((ob == 0).sum())
+            a.run(30)
+            b.run(30)
+            assert np.array_equal(a.cells().view(np.uint32), b.cells().view(np.uint32))
+            assert np.array_equal(a.av_vels(30).view(np.uint32), b.av_vels(30).view(np.uint32))
+        ref = oracle.init_cells(p)
+        oracle.run(p, ref, ob, 30)
+        with lbm.Engine(p, tile, None, n_gpus=slabs, tiled=True) as b:
+            b.run(30)
+            assert np.array_equal(b.cells().view(np.uint32), ref.view(np.uint32))
+
+
+def test_rank_rows_form_equals_global_form(lbm, oracle, monkeypatch):
+    """lbm_create_rank_rows (world of one, RCCL self-exchange): only the rank's rows + periodic neighbour rows
+    are handed over, cells likewise."""
+    monkeypatch.setenv("LBM_FORCE_HALO", "1")
+    p, ob, cells = random_case(lbm, 96, 31, 5, walls=False)
+    h = lbm.MASK_HALO_ROWS
+    rows = np.concatenate([ob[-h:], ob, ob[:h]])            # periodic neighbour rows below and above
+    ref = cells.copy()
+    ref_av = oracle.run(p, ref, ob, 21)
+    with lbm.Engine(p, rows, cells, rank=0, world_size=1, unique_id=lbm.rccl_unique_id(), device=0,
+                    local_rows=True) as eng:
+        assert eng.info()["fluid_cells"] == int((ob == 0).sum())
+        eng.run(21)
+        assert np.array_equal(eng.cells().view(np.uint32), ref.view(np.uint32))
+        np.testing.assert_allclose(eng.av_vels(21), ref_av, rtol=AV_RTOL)
+    tile_p = lbm.Params(96, 62, 10, 10, 0.1, 0.005, 1.85)
+    with lbm.Engine(tile_p, ob, None, rank=0, world_size=1, unique_id=lbm.rccl_unique_id(), device=0,
+                    tiled=True) as eng:
+        assert eng.info()["fluid_cells"] == 2 * int((ob == 0).sum())
