@@ -140,7 +140,7 @@ lbm_ctx* lbm_create_rank(const lbm_params* params, const int* obstacles, const f
  * The mask is built on the device; the fluid-cell count (av_velocity's divisor) is a device reduction over the
  * owned rows summed over the ranks by one all-reduce.  lbm_create and lbm_create_rank count the same way.
  */
-#define LBM_MASK_HALO_ROWS 2
+#define LBM_MASK_HALO_ROWS 3
 lbm_ctx* lbm_create_rank_rows(const lbm_params* params, const int* obstacle_rows, const float* cells_rows_aos,
                               int rank, int world_size, const void* unique_id, int device,
                               int math_mode);

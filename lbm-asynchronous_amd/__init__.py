@@ -31,7 +31,7 @@ MATH_EXACT = 0
 MATH_FAST = 1
 _MATH = {"exact": MATH_EXACT, "fast": MATH_FAST, MATH_EXACT: MATH_EXACT, MATH_FAST: MATH_FAST}
 RCCL_ID_BYTES = 128
-MASK_HALO_ROWS = 2        # LBM_MASK_HALO_ROWS of include/lbm_hip.h
+MASK_HALO_ROWS = 3        # LBM_MASK_HALO_ROWS of include/lbm_hip.h
 HALO_SYNC = 0
 HALO_STALE = 1
 _HALO = {"sync": HALO_SYNC, "stale": HALO_STALE, HALO_SYNC: HALO_SYNC, HALO_STALE: HALO_STALE}

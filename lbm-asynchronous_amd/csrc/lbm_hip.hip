@@ -114,7 +114,7 @@ const TileShape kTileShapes[] = {
     LBM_TILE_SHAPE(64, 8, 2, 704),
 };
 constexpr int kTileShapeCount = (int)(sizeof(kTileShapes) / sizeof(kTileShapes[0]));
-constexpr int kHaloRows = 3;  // halo rows kept below and above every slab (a K-step pass reads K rows beyond the slab)
+constexpr int kHaloRows = 4;  // halo rows kept below and above every slab (a K-step pass reads K rows beyond the slab)
 constexpr int kMaskHalo = LBM_MASK_HALO_ROWS;  // mask rows kept beyond the slab: a K-step pass relaxes K-1 halo rows redundantly
 static_assert(kMaskHalo == kHaloRows - 1, "mask halo");
 
@@ -384,15 +384,11 @@ int launch_stepk(lbm_ctx* c, int s, hipStream_t stream, int k, int row_first, in
   }
   typedef void (*fn)(const lbm::StepKArgs);
   // [math][nontemporal stores][k - 2][prefetch]
-  static const fn table[2][2][2][2] = {
-      {{{lbm::stepk_stream<0, false, 4, 2, false>, lbm::stepk_stream<0, false, 4, 2, true>},
-        {lbm::stepk_stream<0, false, 4, 3, false>, lbm::stepk_stream<0, false, 4, 3, true>}},
-       {{lbm::stepk_stream<0, true, 4, 2, false>, lbm::stepk_stream<0, true, 4, 2, true>},
-        {lbm::stepk_stream<0, true, 4, 3, false>, lbm::stepk_stream<0, true, 4, 3, true>}}},
-      {{{lbm::stepk_stream<1, false, 4, 2, false>, lbm::stepk_stream<1, false, 4, 2, true>},
-        {lbm::stepk_stream<1, false, 4, 3, false>, lbm::stepk_stream<1, false, 4, 3, true>}},
-       {{lbm::stepk_stream<1, true, 4, 2, false>, lbm::stepk_stream<1, true, 4, 2, true>},
-        {lbm::stepk_stream<1, true, 4, 3, false>, lbm::stepk_stream<1, true, 4, 3, true>}}}};
+#define LBM_K_ROW(M, N) {{lbm::stepk_stream<M, N, 4, 2, false>, lbm::stepk_stream<M, N, 4, 2, true>}, \
+                         {lbm::stepk_stream<M, N, 4, 3, false>, lbm::stepk_stream<M, N, 4, 3, true>}, \
+                         {lbm::stepk_stream<M, N, 4, 4, false>, lbm::stepk_stream<M, N, 4, 4, true>}}
+  static const fn table[2][2][3][2] = {{LBM_K_ROW(0, false), LBM_K_ROW(0, true)}, {LBM_K_ROW(1, false), LBM_K_ROW(1, true)}};
+#undef LBM_K_ROW
   const fn kernel = table[c->math_mode == LBM_MATH_EXACT ? 0 : 1][c->nts][k - 2][c->prefetch ? 1 : 0];
   if (done) hipExtLaunchKernelGGL(kernel, dim3(waves), dim3(64), 0, stream, nullptr, done, 0, a);
   else hipLaunchKernelGGL(kernel, dim3(waves), dim3(64), 0, stream, a);
@@ -1144,10 +1140,11 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
   //   (one timestep per pass, step_vec4 / step_scalar: the odd last step of a run, widths that are not a multiple
   //                        of 4, LBM_FUSE2=0; it was the default up to 1.5 Mi cells until the two-step kernel stopped
   //                        computing |u| on its warm-up rows: 768^2 9.8 vs 11.3 us, 1024^2 12.35 vs 13.23, 1152^2 15.3 vs 18.1)
-  //   0.56 .. 6 Mi cells : two timesteps per pass, 2 cells per lane (93 VGPRs, 5 waves/SIMD: twice the
-  //                        waves of the 4-cell form; 1280^2: 19.1 vs 21.2 us, 2048^2: 40 vs 51.5 (one-step))
-  //   >= 6 Mi cells      : two timesteps per pass, 4 cells per lane (16-byte accesses; 8192^2: 517 us vs
-  //                        575 (2-cell) vs 802 (one-step))
+  //   0.56 .. 3 Mi cells : two timesteps per pass, 2 cells per lane (93 VGPRs, 5 waves/SIMD: twice the
+  //                        waves of the 4-cell form; 1280^2: 19.1 vs 21.2 us, 1536^2: 22.2 vs 21.7-25.9 (three-step))
+  //   >= 3 Mi cells      : THREE timesteps per pass, 4 cells per lane (16-byte accesses; us per step, three-step |
+  //                        two-step 4-cell | two-step 2-cell: 1792^2 26.5 | - | 28.8, 2048^2 31.8 | 38.1 | 35.4,
+  //                        2560^2 41.8 | 62.4 | 59.4, 3072^2 59.0 | 76.0 | 90.5, 4096^2 93 | 129, 8192^2 340 | 492)
   // LBM_FUSE2, LBM_LANE_CELLS, LBM_BAND_ROWS override.  Ranks decide from global numbers only, so
   // every rank of a multi-process run takes the same path.
   long min_cells = (long)params->nx * params->ny;
@@ -1158,13 +1155,20 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
   // two timesteps per pass always pay there (1024^2 over 2/4/8 slabs on one device: 45/74/97 us per step
   // vs 70/113/125 one-step; 2048^2 over 8: 96 vs 261).
   c->fuse2 = (c->vec4 && env_int("LBM_FUSE2", (min_cells >= 560L * 1024 || halo_on) ? 1 : 0)) ? 1 : 0;
-  c->lane_cells = env_int("LBM_LANE_CELLS", min_cells >= 6L * 1024 * 1024 ? 4 : 2) == 2 ? 2 : 4;
+  c->lane_cells = env_int("LBM_LANE_CELLS", min_cells >= 3L * 1024 * 1024 ? 4 : 2) == 2 ? 2 : 4;
   c->n_strips = ceil_div(params->nx / c->lane_cells > 0 ? params->nx / c->lane_cells : 1, lbm::kStripQuads);
-  // timesteps per pass of the stream kernel (3 needs the 4-cell form), its prefetch and XCD-chunk flavours
-  c->pass_steps = env_int("LBM_PASS_STEPS", 2);
-  if (c->pass_steps < 2 || c->pass_steps > 3 || c->lane_cells != 4) c->pass_steps = 2;
-  c->prefetch = env_int("LBM_PREFETCH", 0) ? 1 : 0;
-  c->xcd_chunk = env_int("LBM_XCD_CHUNK", 0);
+  // Timesteps per pass of the stream kernel.  The two-step kernel at 8192^2 is bound by DRAM traffic (round-2 PMC),
+  // so the 4-cell form runs THREE steps per pass (stepk_stream<K = 3>: 198-239 VGPRs, 2 waves per SIMD, the next
+  // row prefetched): 8192^2 0.345-0.353 vs 0.466-0.491 ms per step, 16384^2 1.39 vs 2.23, 4096^2 0.103 vs 0.134.
+  // K = 4 (245 VGPRs) is bound by VALU issue and slower (0.361).  The 2-cell form exists for K = 2 only.
+  c->pass_steps = env_int("LBM_PASS_STEPS", c->lane_cells == 4 ? 3 : 2);
+  if (c->pass_steps < 2 || c->pass_steps > kHaloRows || c->lane_cells != 4) c->pass_steps = 2;
+  c->prefetch = env_int("LBM_PREFETCH", c->pass_steps == 3 ? 1 : 0) ? 1 : 0;  // K = 4 + prefetch spills
+  // strips per XCD chunk: half a row of strips, for slabs of many rounds of waves only (12288^2 0.793 vs 0.832 ms per
+  // step, 16384^2 1.369 vs 1.381).  Elsewhere the band height packs the waves tightly into rounds (below) and the
+  // few empty workgroups of the chunked order spill into an extra round (4096^2: 0.135 vs 0.093).
+  const bool many_rounds = (long)c->n_strips * ceil_div(c->row_count / n_slabs, 24) >= 16L * 1024;
+  c->xcd_chunk = env_int("LBM_XCD_CHUNK", (c->pass_steps >= 3 && many_rounds) ? ceil_div(c->n_strips, 2) : 0);
   if (c->xcd_chunk < 0 || c->xcd_chunk > c->n_strips) c->xcd_chunk = 0;
   c->use_stepk = env_int("LBM_STEPK", 0) ? 1 : 0;
   // Band height.  A wave sweeps band_rows + 2 rows.
@@ -1190,6 +1194,26 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
         const long rounds = ((long)c->n_strips * ceil_div(rows_eff, b) + resident - 1) / resident;
         const long cost = rounds * (b + 2);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; pick = (int)b; }
+      }
+    }
+    if (c->lane_cells == 4 && c->pass_steps >= 3) {
+      // K >= 3 (2 waves per SIMD, VALU-bound): the busiest SIMD runs ceil(waves / 1024) waves of band + 2(K-1) row
+      // iterations each, so the cost of a band height is their product (8192^2: 44 rows = 6358 waves -> 7 x 48 =
+      // 0.389 ms per step, 46 rows = 6086 waves -> 6 x 50 = 0.350).  Slabs of many rounds are DRAM-bound and
+      // flat in the height (16384^2: 16 / 24 / 32 / 46 rows = 1.397 / 1.394 / 1.415 / 1.432): 24 rows there.
+      const long interior = (n_slabs > 1 || world > 1 || halo_on) ? rows_eff + 4 - 2 * c->pass_steps : rows_eff;
+      const long r_int = interior > 1 ? interior : 1;
+      const int warm = 2 * (c->pass_steps - 1);
+      if ((long)c->n_strips * ceil_div(r_int, 24) >= 16L * 1024) {
+        pick = 24;
+      } else {
+        long best = -1;
+        for (int b = 8; b <= 64; b++) {
+          const long waves = (long)c->n_strips * ceil_div(r_int, b);
+          const long per_simd = (waves + 1023) / 1024;
+          const long cost = (per_simd < 2 ? 2 : per_simd) * (b + warm);  // a lone wave on a SIMD hides no latency
+          if (best < 0 || cost < best) { best = cost; pick = b; }
+        }
       }
     }
     c->band_rows = env_int("LBM_BAND_ROWS", pick);

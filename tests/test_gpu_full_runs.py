@@ -197,28 +197,33 @@ def test_cli_8192_tiled_run_against_oracle_cli(lbm, oracle, tmp_path):
 
 def test_8192_three_kernels_agree_bitwise_after_1001_steps(lbm, big_case, monkeypatch):
     """Size-independent cross-check at BASELINE's full size: the one-step kernel and the
-    two-steps-per-pass kernel are independent implementations of the same arithmetic (different
-    data flow, different neighbour exchange); after 1001 steps on 8192x8192 (odd: the two-step run
-    ends with a one-step launch) their pressure and velocity fields must be bit-identical and mass
-    conserved."""
+    several-steps-per-pass stream kernels (three steps = the default here, two steps with 4 and with 2
+    cells per lane) are independent implementations of the same arithmetic (different data flow,
+    different neighbour exchange); after 1001 steps on 8192x8192 (1001 = 333 three-step passes + one
+    two-step pass = 500 two-step passes + a one-step launch) their pressure and velocity fields must be
+    bit-identical and mass conserved."""
     p0, ob = big_case
     p = lbm.Params(p0.nx, p0.ny, 1001, p0.reynolds_dim, p0.density, p0.accel, p0.omega)
     out = {}
-    for fuse, lane_cells in (("0", "4"), ("1", "4"), ("1", "2")):
+    for tag, fuse, lane_cells, pass_steps, spl in (("one", "0", "4", "3", 1), ("three", "1", "4", "3", 3),
+                                                   ("two4", "1", "4", "2", 2), ("two2", "1", "2", "2", 2)):
         monkeypatch.setenv("LBM_FUSE2", fuse)
         monkeypatch.setenv("LBM_LANE_CELLS", lane_cells)
+        monkeypatch.setenv("LBM_PASS_STEPS", pass_steps)
         with lbm.Engine(p, ob, None) as eng:
-            assert eng.info()["steps_per_launch"] == (2 if fuse == "1" else 1)
+            assert eng.info()["steps_per_launch"] == spl
             m0 = eng.total_density()
             eng.run(1001)
             assert eng.total_density() == pytest.approx(m0, rel=1e-6)
             f = eng.final_state()
-            out[fuse + lane_cells] = (f["pressure"].copy(), f["u"].copy(), eng.av_vels(1001))
-    for other in ("14", "12"):      # two-step kernel with 4 and with 2 cells per lane
-        assert np.array_equal(out["04"][0].view(np.uint32), out[other][0].view(np.uint32))
-        assert np.array_equal(out["04"][1].view(np.uint32), out[other][1].view(np.uint32))
-        np.testing.assert_allclose(out["04"][2], out[other][2], rtol=1e-6)
-    assert np.isfinite(out["14"][2]).all() and out["14"][2][-1] > out["14"][2][0] > 0
+            out[tag] = (f["pressure"].copy(), f["u"].copy(), eng.av_vels(1001))
+    for other in ("three", "two4", "two2"):
+        assert np.array_equal(out["one"][0].view(np.uint32), out[other][0].view(np.uint32)), other
+        assert np.array_equal(out["one"][1].view(np.uint32), out[other][1].view(np.uint32)), other
+        # the stream kernels take |u| from the pre-collision moments (same lattice, ~1e-7 per cell): while the
+        # flow is still tiny (|u| ~ 3e-7 in the first steps) the average moves by up to 1.4e-5 relative
+        np.testing.assert_allclose(out["one"][2], out[other][2], rtol=5e-5)
+    assert np.isfinite(out["three"][2]).all() and out["three"][2][-1] > out["three"][2][0] > 0
 
 
 def test_8192_properties(lbm, big_case):
@@ -234,8 +239,8 @@ def test_8192_properties(lbm, big_case):
         # splitting the run changes nothing, bit for bit
         for n in (1, 7, 32):
             split.run(n)
-        np.testing.assert_allclose(split.av_vels(40), av, rtol=1e-6)   # summation order only
-        assert eng.av_velocity() == pytest.approx(float(av[-1]), rel=1e-6)
+        np.testing.assert_allclose(split.av_vels(40), av, rtol=5e-5)   # summation order, and |u| from pre- vs
+        assert eng.av_velocity() == pytest.approx(float(av[-1]), rel=5e-5)   # post-collision moments by kernel
         a = eng.final_state()["pressure"]
         b = split.final_state()["pressure"]
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
@@ -267,4 +272,4 @@ def test_16384_slabs_and_kernels_agree_bitwise(lbm, monkeypatch):
             continue
         for k in range(3):
             assert np.array_equal(want[k].view(np.uint32), got[k].view(np.uint32)), (label, k)
-        np.testing.assert_allclose(got[3], want[3], rtol=1e-6)
+        np.testing.assert_allclose(got[3], want[3], rtol=5e-5)
