@@ -59,11 +59,11 @@ def synthetic_case(lbm, nx, ny, steps):
         p = lbm.read_params(own)
         ob = lbm.read_obstacles(os.path.join(inputs, f"obstacles_{nx}x{ny}.dat"), nx, ny)
         p.max_iters = steps
-        return p, ob, f"reference data set {nx}x{ny}"
+        return p, ob, f"reference data set {nx}x{ny}", False
+    # the engine expands the tile on the device (lbm_create_tiled): no nx*ny int map on the host
     tile = lbm.read_obstacles(os.path.join(inputs, "obstacles_1024x1024.dat"), 1024, 1024)
-    ob = lbm.tile_obstacles(tile, nx, ny)
     p = lbm.Params(nx, ny, steps, 10, 0.1, 0.01, 1.85)
-    return p, ob, f"synthetic {nx}x{ny}: 1024x1024 obstacle map tiled {nx // 1024}x{ny // 1024}"
+    return p, tile, f"synthetic {nx}x{ny}: 1024x1024 obstacle map tiled {nx // 1024}x{ny // 1024}", True
 
 
 def cpu_baseline(nx, ny, budget_s=20.0):
@@ -237,13 +237,13 @@ def main():
     if use_rank_api:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    def make_engine(p, ob):
+    def make_engine(p, ob, tiled):
         if not use_rank_api:
-            return lbm.Engine(p, ob, None, n_gpus=1, math=args.math)
+            return lbm.Engine(p, ob, None, n_gpus=1, math=args.math, tiled=tiled)
         uid = [lbm.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         return lbm.Engine(p, ob, None, math=args.math, rank=rank, world_size=world,
-                          unique_id=uid[0], device=local_rank)
+                          unique_id=uid[0], device=local_rank, tiled=tiled)
 
     check = {}
     also = {}
@@ -338,7 +338,7 @@ def main():
 
     extras_timeout = float(os.environ.get("LBM_BENCH_EXTRA_TIMEOUT", "300"))
 
-    def verify_against_single_gpu(p, ob, eng, av, total):
+    def verify_against_single_gpu(p, ob, tiled, eng, av, total):
         """After the timed region of a multi-rank run: every rank re-runs the SAME workload as one
         periodic slab on its own GPU and compares its rows of the final u_x, u_y, |u| and pressure
         fields bit for bit, and the all-reduced av_vels (which differ by summation order only)."""
@@ -347,7 +347,7 @@ def main():
         forced = os.environ.pop("LBM_FORCE_HALO", None)     # the reference run is a plain periodic slab
         try:
             with lbm.Engine(p, ob, None, math=args.math, rank=0, world_size=1,
-                            unique_id=lbm.rccl_unique_id(), device=local_rank) as ref:
+                            unique_id=lbm.rccl_unique_id(), device=local_rank, tiled=tiled) as ref:
                 ref.run(total)
                 ref_av = ref.av_vels(total)
                 whole = ref.final_state()
@@ -370,8 +370,8 @@ def main():
         `n_repeats` timed regions of `steps` timesteps each: barrier + device sync on both sides, max over
         ranks.  Returns the median region: (seconds, kernel ms per step, engine info, av_vels finite, workload)."""
         prewarm_cap = 40000
-        p, ob, workload = synthetic_case(lbm, gx, gy, warmup + prewarm_cap + n_repeats * steps)
-        eng = make_engine(p, ob)
+        p, ob, workload, tiled = synthetic_case(lbm, gx, gy, warmup + prewarm_cap + n_repeats * steps)
+        eng = make_engine(p, ob, tiled)
 
         def fence():
             eng.sync()
@@ -436,7 +436,7 @@ def main():
             watchdog.start()
         if verify:
             try:
-                verify_against_single_gpu(p, ob, eng, av, done)
+                verify_against_single_gpu(p, ob, tiled, eng, av, done)
             except Exception as exc:
                 check.update({"error": str(exc), "fields_bitwise_equal_to_single_gpu_run": False})
         eng.close()

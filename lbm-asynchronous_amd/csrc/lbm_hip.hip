@@ -85,13 +85,15 @@ struct Slab {
   float* partials = nullptr;  // kPartSlots x part_stride
   double* tot_u = nullptr;    // capacity entries: per-step sum of |u| over this slab
   double* scratch = nullptr;  // 2 x kSumBlocks doubles for lattice_sums
+  double* reduce_buf = nullptr;  // ranked contexts: capacity doubles for the av_vels all-reduce
   int* flushed_dev = nullptr; // graph replay: index of the first step of the chunk being reduced
   hipGraphExec_t chunk_graph[2] = {nullptr, nullptr};  // kPartSlots timesteps + their reduce, by lattice parity
   hipStream_t compute = nullptr, comm = nullptr;
   hipEvent_t ev_boundary = nullptr, ev_halo = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
   hipEvent_t ev_interior[2] = {nullptr, nullptr};  // interior kernel of step t -> [t & 1]
   hipEvent_t ev_flush = nullptr;                   // partials reduced: their slots may be reused
-  hipEvent_t ev_step = nullptr;                    // stale-halo mode: whole-slab pass finished
+  hipEvent_t ev_step = nullptr;                    // stale-halo mode: whole-slab pass finished; graph replay: join
+  hipEvent_t ev_fork = nullptr;                    // graph replay: the other streams join the capture / follow the chunks
   hipEvent_t ev_x[2] = {nullptr, nullptr};         // stale-halo mode: exchange for pass m landed -> [(m + 1) & 1]
   ncclComm_t nccl = nullptr;
   lbm::SlotCounts slot_counts;  // partials written into each buffered slot (launch geometries differ)
@@ -233,7 +235,7 @@ struct lbm_ctx {
   int band_rows = 8, n_strips = 0;  // step2_stream geometry: band height, waves across x
   int lane_cells = 4;               // cells per lane in step2_stream (4 or 2; LBM_LANE_CELLS)
   SlabTeam* team = nullptr;         // one issuing thread per slab (one-process multi-GPU), or null
-  int use_graph = 0;                // single slab: replay kPartSlots timesteps + reduce as one hipGraph
+  int use_graph = 0;                // replay chunks of an even number of passes + their reduce as one hipGraph each
   int tile_steps = 0;               // > 0: single slab advanced by the LDS-tile kernel, this many steps per launch
   int tile_shape = 0;               // index into kTileShapes
 };
@@ -553,69 +555,6 @@ int flush_partials(lbm_ctx* c, int step_base) {
   });
 }
 
-// ---- hipGraph replay of the launch-bound loop (single periodic slab) ----------------------------------
-// kPartSlots timesteps and the reduce of their partial sums are captured once per lattice parity and
-// replayed with one hipGraphLaunch each.  All launch arguments of a chunk are the same every time
-// (an even number of passes returns to the same lattice, the partial slots are reused) except the index
-// of the chunk's first step in tot_u, which the reduce kernel reads from device memory.  Every pass
-// of a chunk applies the next step's acceleration, so a chunk is only replayed while at least one more
-// timestep follows it in the same lbm_run call.
-int capture_chunk(lbm_ctx* c, hipGraphExec_t* out) {
-  Slab& sl = c->slab[0];
-  const int saved_cur = c->cur, saved_fill = c->slot_fill;
-  hipGraph_t graph = nullptr;
-  HIP_TRY(LBM_FAILURE, hipStreamBeginCapture(sl.compute, hipStreamCaptureModeThreadLocal));
-  int rc = LBM_SUCCESS;
-  c->slot_fill = 0;
-  for (int t = 0; t < kPartSlots && rc == LBM_SUCCESS;) {
-    const int adv = c->tile_steps ? c->tile_steps : (c->fuse2 ? 2 : 1);
-    int n_part;
-    if (c->tile_steps) {
-      rc = launch_tile(c, sl.compute, adv, true);
-      n_part = tile_count(c);
-    } else if (c->fuse2) {
-      rc = launch_pass(c, 0, sl.compute, 2, 0, sl.rows, c->band_rows, c->band_rows, ceil_div(sl.rows, c->band_rows), 0, true);
-      n_part = c->n_strips * ceil_div(sl.rows, c->band_rows);
-    } else {
-      rc = launch_step(c, 0, sl.compute, 0, 1, sl.rows, 0, true);
-      n_part = sl.blocks_main;
-    }
-    for (int k = 0; k < adv; k++) sl.slot_counts.n[c->slot_fill + k] = n_part;
-    c->cur ^= 1;
-    c->slot_fill += adv;
-    t += adv;
-  }
-  if (rc == LBM_SUCCESS) {
-    hipLaunchKernelGGL(lbm::reduce_partials, dim3(kPartSlots), dim3(lbm::kBlock), 0, sl.compute, sl.partials,
-                       sl.slot_counts, c->part_stride, sl.tot_u, 0, (const int*)sl.flushed_dev);
-    hipLaunchKernelGGL(lbm::advance_counter, dim3(1), dim3(1), 0, sl.compute, sl.flushed_dev, kPartSlots);
-  }
-  const hipError_t end = hipStreamEndCapture(sl.compute, &graph);
-  c->cur = saved_cur;  // an even number of passes
-  c->slot_fill = saved_fill;
-  if (rc != LBM_SUCCESS) { if (graph) (void)hipGraphDestroy(graph); return LBM_FAILURE; }
-  HIP_TRY(LBM_FAILURE, end);
-  const hipError_t inst = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
-  (void)hipGraphDestroy(graph);
-  HIP_TRY(LBM_FAILURE, inst);
-  return LBM_SUCCESS;
-}
-
-// replays as many whole chunks as fit in front of the last timestep of this call; returns the timesteps done
-int replay_chunks(lbm_ctx* c, int n_steps, int first_step, int* done) {
-  *done = 0;
-  Slab& sl = c->slab[0];
-  const int n_chunks = (n_steps - 1) / kPartSlots;
-  if (n_chunks <= 0 || c->slot_fill != 0) return LBM_SUCCESS;
-  hipGraphExec_t& exec = sl.chunk_graph[c->cur];
-  if (!exec && capture_chunk(c, &exec) != LBM_SUCCESS) return LBM_FAILURE;
-  hipLaunchKernelGGL(lbm::set_counter, dim3(1), dim3(1), 0, sl.compute, sl.flushed_dev, first_step);
-  HIP_TRY(LBM_FAILURE, hipGetLastError());
-  for (int k = 0; k < n_chunks; k++) HIP_TRY(LBM_FAILURE, hipGraphLaunch(exec, sl.compute));
-  *done = n_chunks * kPartSlots;
-  return LBM_SUCCESS;
-}
-
 // the slab threads spin between phases while a run is in flight
 struct HotGuard {
   SlabTeam* t;
@@ -644,7 +583,7 @@ int read_step_timing(lbm_ctx* c, int n_steps, float* kernel_ms) {
   return LBM_SUCCESS;
 }
 
-// The timestep loop.  Single slab: one fused launch per pass (one or two timesteps).  Several slabs / ranks
+// The timestep loop.  Single slab: one fused launch per pass (one to four timesteps).  Several slabs / ranks
 // (the Waitall pattern of MPI_Waitall/d2q9-bgk.c:225-253, restructured for two HIP streams):
 //
 //   compute stream:  I(0) ─────────────► I(1) ─────────────► I(2) ...     rows that touch no halo row
@@ -656,9 +595,223 @@ int read_step_timing(lbm_ctx* c, int n_steps, float* kernel_ms) {
 // needs the halos X(m) (its own stream, in order) and writes the boundary rows X(m+1) sends.  The
 // chain of interior kernels is the critical path; exchange and boundary rows hide beside it.
 //
-// Two-step passes across slabs: an output row y reads source rows y-2 .. y+2, so only rows 0,1 and
-// rows-2, rows-1 touch halo rows.  They form two 2-row bands (short sweeps: low latency on the comm
-// stream); rows [2, rows-2) are the interior region, cut into bands of band_rows.
+// K-step passes across slabs: an output row y reads source rows y-K .. y+K, so only rows [0, K) and
+// [rows-K, rows) touch halo rows.  They form two K-row bands (short sweeps: low latency on the comm
+// stream); rows [K, rows-K) are the interior region, cut into bands of band_rows.
+
+// Pipeline events in a defined state: "I(-1)" = the lattice is ready (also orders the comm stream after everything
+// on the compute stream), "B(-1)" done.  Called at the start of a run and after a graph replay (events recorded
+// inside a stream capture cannot be waited for outside it).
+int reset_pipeline(lbm_ctx* c) {
+  return for_slabs(c, [&](int s) -> int {
+    Slab& sl = c->slab[s];
+    HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+    HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_interior[1], sl.compute));
+    HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sl.ev_interior[1], 0));
+    HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_boundary, sl.comm));
+    if (c->halo == HALO_MEMCPY) HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_halo, sl.comm));
+    return LBM_SUCCESS;
+  });
+}
+
+// Pass m of the pipeline: X(m) (with halos), I(m), B(m), and the bookkeeping of the partial slots it fills.
+//   tile > 0: that many timesteps of the LDS-tile kernel;  k >= 2: a k-step pass of the stream kernel;  else one step.
+//   accel_after: apply the acceleration of the step after this pass (false on the last pass of an lbm_run call).
+//   bound_events: bind the pipeline events to the kernels' own completion signals (hipExtLaunchKernel); not inside a
+//   stream capture, where hipEventRecord costs nothing (it becomes a graph edge).
+int issue_pass(lbm_ctx* c, int m, int tile, int k, bool accel_after, bool bound_events) {
+  const bool halo = (c->halo != HALO_SELF);
+  const int adv = tile ? tile : (k ? k : 1);
+  const int depth = c->fuse2 ? c->pass_steps : 1;  // a K-step pass reads K rows beyond the slab
+  if (halo && exchange_halos(c, depth, c->cur, c->cur, -1) != LBM_SUCCESS) return LBM_FAILURE;
+  // phase 1: rows that touch no halo row (or the whole slab) on the compute streams
+  if (for_slabs(c, [&](int s) -> int {
+        Slab& sl = c->slab[s];
+        HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+        if (halo && m > 0) HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, sl.ev_boundary, 0));  // B(m-1)
+        hipEvent_t done = (halo && bound_events) ? sl.ev_interior[m & 1] : nullptr;  // I(m) done
+        if (tile) {
+          if (launch_tile(c, sl.compute, tile, accel_after) != LBM_SUCCESS) return LBM_FAILURE;
+        } else if (k) {
+          const int r0 = halo ? k : 0, r1 = halo ? sl.rows - k : sl.rows;
+          if (launch_pass(c, s, sl.compute, k, r0, r1, c->band_rows, c->band_rows, ceil_div(r1 - r0, c->band_rows), 0,
+                          accel_after, done) != LBM_SUCCESS)
+            return LBM_FAILURE;
+        } else if (!halo) {
+          if (launch_step(c, s, sl.compute, 0, 1, sl.rows, 0, accel_after) != LBM_SUCCESS) return LBM_FAILURE;
+        } else {
+          if (launch_step(c, s, sl.compute, 1, 1, sl.rows - 2, 0, accel_after, done) != LBM_SUCCESS) return LBM_FAILURE;
+        }
+        if (halo && !done) HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_interior[m & 1], sl.compute));
+        return LBM_SUCCESS;
+      }) != LBM_SUCCESS)
+    return LBM_FAILURE;
+  // phase 2: halo-touching rows / bands on the comm streams, behind the exchange X(m)
+  if (halo &&
+      for_slabs(c, [&](int s) -> int {
+        Slab& sl = c->slab[s];
+        HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+        HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sl.ev_interior[(m + 1) & 1], 0));  // I(m-1)
+        if (c->halo == HALO_MEMCPY) {
+          const int north = (s + 1) % c->n_slabs, south = (s - 1 + c->n_slabs) % c->n_slabs;
+          HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, c->slab[north].ev_halo, 0));
+          HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, c->slab[south].ev_halo, 0));
+        }
+        hipEvent_t bdone = bound_events ? sl.ev_boundary : nullptr;  // B(m) done
+        if (k) {
+          // rows [0, k) and [rows-k, rows) as two k-row bands in one launch
+          const int off = c->n_strips * ceil_div(sl.rows - 2 * k, c->band_rows);
+          if (launch_pass(c, s, sl.comm, k, 0, sl.rows, k, sl.rows - k, 2, off, accel_after, bdone) != LBM_SUCCESS) return LBM_FAILURE;
+        } else {
+          if (launch_step(c, s, sl.comm, 0, sl.rows - 1, 2, sl.blocks_main, accel_after, bdone) != LBM_SUCCESS) return LBM_FAILURE;
+        }
+        if (!bdone) HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_boundary, sl.comm));
+        return LBM_SUCCESS;
+      }) != LBM_SUCCESS)
+    return LBM_FAILURE;
+  // bookkeeping of the partial slots written by this pass
+  for (int s = 0; s < c->n_slabs; s++) {
+    Slab& sl = c->slab[s];
+    const int fused_waves = halo ? c->n_strips * (ceil_div(sl.rows - 2 * k, c->band_rows) + 2)
+                                 : c->n_strips * ceil_div(sl.rows, c->band_rows);
+    const int n_part = tile ? tile_count(c) : (k ? fused_waves : sl.blocks_main + sl.blocks_boundary);
+    for (int j = 0; j < adv; j++) sl.slot_counts.n[c->slot_fill + j] = n_part;
+  }
+  c->cur ^= 1;
+  c->slot_fill += adv;
+  return LBM_SUCCESS;
+}
+
+// ---- hipGraph replay of the timestep loop ---------------------------------------------------------------------
+// A chunk = an even number of passes (so that it starts and ends on the same lattice buffer) and the reduce of
+// their partial sums, captured ONCE per lattice parity -- both streams of every slab, the halo exchange (RCCL
+// send/recv or device copies) inside the capture -- and replayed with one hipGraphLaunch (BASELINE.json
+// configs[4]: "double-buffered halos + hipGraph-captured timestep").  All launch arguments of a chunk are the same
+// every time except the index of the chunk's first step in tot_u, which the reduce kernel reads from device memory.
+// Every pass of a chunk applies the next step's acceleration, so a chunk is only replayed while at least one more
+// timestep follows it in the same lbm_run call.  A chunk begins with its own exchange X(0) and ends with every
+// stream joined, i.e. one exchange per chunk is not hidden behind interior rows (1 of 20-32).
+// The capture starts on slab 0's compute stream; every other stream joins it through an event.
+int chunk_passes(const lbm_ctx* c, int* steps_per_pass) {
+  const int halo = (c->halo != HALO_SELF);
+  const int adv = (!halo && c->tile_steps) ? c->tile_steps : (c->fuse2 ? c->pass_steps : 1);
+  int passes = kPartSlots / adv;
+  static const int cap = env_int("LBM_GRAPH_PASSES", 0);  // experiments: shorter chunks
+  if (cap > 0 && passes > cap) passes = cap;
+  passes -= passes & 1;
+  *steps_per_pass = adv;
+  return passes;
+}
+
+int capture_chunk(lbm_ctx* c, hipGraphExec_t* out) {
+  const bool halo = (c->halo != HALO_SELF);
+  int adv;
+  const int passes = chunk_passes(c, &adv);
+  if (passes < 2) LBM_FAIL(LBM_FAILURE, "hipGraph chunk: no even number of passes fits");
+  const int tile = (!halo && c->tile_steps) ? c->tile_steps : 0;
+  const int k = (!tile && c->fuse2) ? c->pass_steps : 0;
+  Slab& s0 = c->slab[0];
+  const int saved_cur = c->cur, saved_fill = c->slot_fill;
+  hipGraph_t graph = nullptr;
+  HIP_TRY(LBM_FAILURE, hipSetDevice(s0.device));
+  HIP_TRY(LBM_FAILURE, hipStreamBeginCapture(s0.compute, halo ? hipStreamCaptureModeRelaxed : hipStreamCaptureModeThreadLocal));
+  int rc = LBM_SUCCESS;
+  auto step = [&](hipError_t e) { if (e != hipSuccess && rc == LBM_SUCCESS) { raise_error(__LINE__, "HIP error during graph capture: %s", hipGetErrorString(e)); rc = LBM_FAILURE; } };
+  // fork: every other stream of the context joins the capture
+  step(hipEventRecord(s0.ev_fork, s0.compute));
+  for (int s = 0; s < c->n_slabs && rc == LBM_SUCCESS; s++) {
+    Slab& sl = c->slab[s];
+    if (s > 0) step(hipStreamWaitEvent(sl.compute, s0.ev_fork, 0));
+    if (halo) step(hipStreamWaitEvent(sl.comm, s0.ev_fork, 0));
+  }
+  c->slot_fill = 0;
+  if (halo && rc == LBM_SUCCESS) {
+    // pipeline events of pass 0 in a defined (captured) state
+    for (int s = 0; s < c->n_slabs && rc == LBM_SUCCESS; s++) {
+      Slab& sl = c->slab[s];
+      step(hipEventRecord(sl.ev_interior[1], sl.compute));
+      step(hipEventRecord(sl.ev_boundary, sl.comm));
+      if (c->halo == HALO_MEMCPY) step(hipEventRecord(sl.ev_halo, sl.comm));
+    }
+  }
+  for (int m = 0; m < passes && rc == LBM_SUCCESS; m++) rc = issue_pass(c, m, tile, k, true, false);
+  if (rc == LBM_SUCCESS) {
+    for (int s = 0; s < c->n_slabs; s++) {
+      Slab& sl = c->slab[s];
+      if (halo) step(hipStreamWaitEvent(sl.compute, sl.ev_boundary, 0));  // the boundary rows' partials
+      hipLaunchKernelGGL(lbm::reduce_partials, dim3(c->slot_fill), dim3(lbm::kBlock), 0, sl.compute, sl.partials,
+                         sl.slot_counts, c->part_stride, sl.tot_u, 0, (const int*)sl.flushed_dev);
+      hipLaunchKernelGGL(lbm::advance_counter, dim3(1), dim3(1), 0, sl.compute, sl.flushed_dev, c->slot_fill);
+      // join: back into slab 0's compute stream
+      if (halo) {
+        step(hipEventRecord(sl.ev_flush, sl.comm));
+        step(hipStreamWaitEvent(s0.compute, sl.ev_flush, 0));
+      }
+      if (s > 0) {
+        step(hipEventRecord(sl.ev_step, sl.compute));
+        step(hipStreamWaitEvent(s0.compute, sl.ev_step, 0));
+      }
+    }
+  }
+  const hipError_t end = hipStreamEndCapture(s0.compute, &graph);
+  c->cur = saved_cur;  // an even number of passes
+  c->slot_fill = saved_fill;
+  if (rc != LBM_SUCCESS) { if (graph) (void)hipGraphDestroy(graph); return LBM_FAILURE; }
+  HIP_TRY(LBM_FAILURE, end);
+  const hipError_t inst = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  HIP_TRY(LBM_FAILURE, inst);
+  return LBM_SUCCESS;
+}
+
+// replays as many whole chunks as fit in front of the last timestep of this call; returns the timesteps done
+int replay_chunks(lbm_ctx* c, int n_steps, int first_step, int* done) {
+  *done = 0;
+  int adv;
+  const int chunk_steps = chunk_passes(c, &adv) * adv;
+  if (chunk_steps <= 0) return LBM_SUCCESS;
+  const int n_chunks = (n_steps - 1) / chunk_steps;
+  if (n_chunks <= 0 || c->slot_fill != 0) return LBM_SUCCESS;
+  Slab& s0 = c->slab[0];
+  hipGraphExec_t& exec = s0.chunk_graph[c->cur];
+  if (!exec && capture_chunk(c, &exec) != LBM_SUCCESS) {
+    // e.g. a runtime that cannot capture across devices: go on launch by launch
+    fprintf(stderr, "lbm_hip: hipGraph capture failed (%s); continuing with stream launches\n", g_last_error);
+    exec = nullptr;
+    c->use_graph = 0;
+    return LBM_SUCCESS;
+  }
+  // everything enqueued so far on the other streams precedes the chunks, which run "on" slab 0's compute stream
+  for (int s = 0; s < c->n_slabs; s++) {
+    Slab& sl = c->slab[s];
+    HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+    hipLaunchKernelGGL(lbm::set_counter, dim3(1), dim3(1), 0, sl.compute, sl.flushed_dev, first_step);
+    HIP_TRY(LBM_FAILURE, hipGetLastError());
+    if (s > 0) {
+      HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_step, sl.compute));
+      HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(s0.compute, sl.ev_step, 0));
+    }
+    if (c->halo != HALO_SELF) {
+      HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_flush, sl.comm));
+      HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(s0.compute, sl.ev_flush, 0));
+    }
+  }
+  HIP_TRY(LBM_FAILURE, hipSetDevice(s0.device));
+  for (int k = 0; k < n_chunks; k++) HIP_TRY(LBM_FAILURE, hipGraphLaunch(exec, s0.compute));
+  // ... and everything that follows on the other streams comes after them
+  if (c->n_slabs > 1 || c->halo != HALO_SELF) {
+    HIP_TRY(LBM_FAILURE, hipEventRecord(s0.ev_fork, s0.compute));
+    for (int s = 0; s < c->n_slabs; s++) {
+      Slab& sl = c->slab[s];
+      HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+      if (s > 0) HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, s0.ev_fork, 0));
+      if (c->halo != HALO_SELF) HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, s0.ev_fork, 0));
+    }
+  }
+  *done = n_chunks * chunk_steps;
+  return LBM_SUCCESS;
+}
+
 int run_steps_stale(lbm_ctx* c, int n_steps, float* kernel_ms);
 
 int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
@@ -686,98 +839,30 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
                              sl.accel_row, a1, a2);
           HIP_TRY(LBM_FAILURE, hipGetLastError());
         }
-        if (halo) {
-          // "I(-1)": the lattice is ready; also orders the comm stream after everything a previous
-          // lbm_run left on the compute stream
-          HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_interior[1], sl.compute));
-          HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sl.ev_interior[1], 0));
-          // boundary event in a defined state for the first memcpy exchange
-          HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_boundary, sl.comm));
-        }
         if (kernel_ms) HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_t0, sl.compute));
         return LBM_SUCCESS;
       }) != LBM_SUCCESS)
     return LBM_FAILURE;
-  // halo depth: a K-step pass reads K rows beyond the slab
-  const int depth = c->fuse2 ? c->pass_steps : 1;
-  if (halo && exchange_halos(c, depth, c->cur, c->cur, -1) != LBM_SUCCESS) return LBM_FAILURE;
 
-  // macro steps: pass_steps timesteps per pass where enabled and that many remain, else two, else one
   int flushed_upto = c->steps_done;
   int t_first = 0;
-  if (!halo && c->use_graph) {
+  if (c->use_graph) {
     if (replay_chunks(c, n_steps, flushed_upto, &t_first) != LBM_SUCCESS) return LBM_FAILURE;
     flushed_upto += t_first;
   }
+  if (halo && reset_pipeline(c) != LBM_SUCCESS) return LBM_FAILURE;
+
+  // passes launch by launch: pass_steps timesteps per pass where enabled and that many remain, else two, else one
+  static const int ext_events = env_int("LBM_EXT_EVENTS", 1);
   const int slots_per_pass = c->tile_steps > c->pass_steps ? c->tile_steps : c->pass_steps;
-  int m = 0;  // macro step counter (event parity)
+  int m = 0;  // pass counter (event parity)
   for (int t = t_first; t < n_steps; m++) {
     const int tile = (!halo && c->tile_steps) ? (c->tile_steps < n_steps - t ? c->tile_steps : n_steps - t) : 0;
-    // timesteps of this pass through the stream kernel (0: another kernel)
     const int k = (!tile && c->fuse2 && n_steps - t >= 2) ? (n_steps - t >= c->pass_steps ? c->pass_steps : 2) : 0;
     const int adv = tile ? tile : (k ? k : 1);
     const bool last = (t + adv == n_steps);
-    // phase 1: rows that touch no halo row (or the whole slab) on the compute streams
-    if (for_slabs(c, [&](int s) -> int {
-          Slab& sl = c->slab[s];
-          HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
-          if (halo && m > 0) HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, sl.ev_boundary, 0));  // B(m-1)
-          static const int ext_events = env_int("LBM_EXT_EVENTS", 1);
-          hipEvent_t done = (halo && ext_events) ? sl.ev_interior[m & 1] : nullptr;  // I(m) done
-          if (tile) {
-            if (launch_tile(c, sl.compute, tile, !last) != LBM_SUCCESS) return LBM_FAILURE;
-          } else if (k) {
-            const int r0 = halo ? k : 0, r1 = halo ? sl.rows - k : sl.rows;
-            if (launch_pass(c, s, sl.compute, k, r0, r1, c->band_rows, c->band_rows, ceil_div(r1 - r0, c->band_rows), 0,
-                            !last, done) != LBM_SUCCESS)
-              return LBM_FAILURE;
-          } else if (!halo) {
-            if (launch_step(c, s, sl.compute, 0, 1, sl.rows, 0, !last) != LBM_SUCCESS) return LBM_FAILURE;
-          } else {
-            if (launch_step(c, s, sl.compute, 1, 1, sl.rows - 2, 0, !last, done) != LBM_SUCCESS) return LBM_FAILURE;
-          }
-          if (halo && !done) HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_interior[m & 1], sl.compute));
-          return LBM_SUCCESS;
-        }) != LBM_SUCCESS)
-      return LBM_FAILURE;
-    // phase 2: halo-touching rows / bands on the comm streams, behind the exchange X(m)
-    if (halo &&
-        for_slabs(c, [&](int s) -> int {
-          Slab& sl = c->slab[s];
-          HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
-          HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sl.ev_interior[(m + 1) & 1], 0));  // I(m-1)
-          if (c->halo == HALO_MEMCPY) {
-            const int north = (s + 1) % c->n_slabs, south = (s - 1 + c->n_slabs) % c->n_slabs;
-            HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, c->slab[north].ev_halo, 0));
-            HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, c->slab[south].ev_halo, 0));
-          }
-          static const int ext_events_b = env_int("LBM_EXT_EVENTS", 1);
-          hipEvent_t bdone = ext_events_b ? sl.ev_boundary : nullptr;  // B(m) done
-          if (k) {
-            // rows [0, k) and [rows-k, rows) as two k-row bands in one launch
-            const int off = c->n_strips * ceil_div(sl.rows - 2 * k, c->band_rows);
-            if (launch_pass(c, s, sl.comm, k, 0, sl.rows, k, sl.rows - k, 2, off, !last, bdone) != LBM_SUCCESS) return LBM_FAILURE;
-          } else {
-            if (launch_step(c, s, sl.comm, 0, sl.rows - 1, 2, sl.blocks_main, !last, bdone) != LBM_SUCCESS) return LBM_FAILURE;
-          }
-          if (!bdone) HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_boundary, sl.comm));
-          return LBM_SUCCESS;
-        }) != LBM_SUCCESS)
-      return LBM_FAILURE;
-    // bookkeeping of the partial slots written by this macro step
-    for (int s = 0; s < c->n_slabs; s++) {
-      Slab& sl = c->slab[s];
-      const int fused_waves = halo ? c->n_strips * (ceil_div(sl.rows - 2 * k, c->band_rows) + 2)
-                                   : c->n_strips * ceil_div(sl.rows, c->band_rows);
-      const int n_part = tile ? tile_count(c)
-                              : (k ? fused_waves : sl.blocks_main + sl.blocks_boundary);
-      for (int j = 0; j < adv; j++) sl.slot_counts.n[c->slot_fill + j] = n_part;
-    }
-    c->cur ^= 1;
-    c->slot_fill += adv;
+    if (issue_pass(c, m, tile, k, !last, ext_events != 0) != LBM_SUCCESS) return LBM_FAILURE;
     t += adv;
-    // phase 3: the next exchange
-    if (halo && !last && exchange_halos(c, depth, c->cur, c->cur, -1) != LBM_SUCCESS) return LBM_FAILURE;
     if (c->slot_fill + slots_per_pass > kPartSlots || last) {
       if (flush_partials(c, flushed_upto) != LBM_SUCCESS) return LBM_FAILURE;
       flushed_upto += c->slot_fill;
@@ -889,6 +974,7 @@ void free_slab(Slab& sl) {
   if (sl.partials) (void)hipFree(sl.partials);
   if (sl.tot_u) (void)hipFree(sl.tot_u);
   if (sl.scratch) (void)hipFree(sl.scratch);
+  if (sl.reduce_buf) (void)hipFree(sl.reduce_buf);
   if (sl.flushed_dev) (void)hipFree(sl.flushed_dev);
   for (int i = 0; i < 2; i++) if (sl.chunk_graph[i]) (void)hipGraphExecDestroy(sl.chunk_graph[i]);
   if (sl.ev_boundary) (void)hipEventDestroy(sl.ev_boundary);
@@ -896,6 +982,7 @@ void free_slab(Slab& sl) {
   for (int i = 0; i < 2; i++) if (sl.ev_interior[i]) (void)hipEventDestroy(sl.ev_interior[i]);
   if (sl.ev_flush) (void)hipEventDestroy(sl.ev_flush);
   if (sl.ev_step) (void)hipEventDestroy(sl.ev_step);
+  if (sl.ev_fork) (void)hipEventDestroy(sl.ev_fork);
   for (int i = 0; i < 2; i++) if (sl.ev_x[i]) (void)hipEventDestroy(sl.ev_x[i]);
   if (sl.ev_t0) (void)hipEventDestroy(sl.ev_t0);
   if (sl.ev_t1) (void)hipEventDestroy(sl.ev_t1);
@@ -921,6 +1008,7 @@ int build_slab(lbm_ctx* c, int s, const ObstacleSource& obst, const float* cells
   for (int i = 0; i < 2; i++) HIP_TRY(LBM_FAILURE, hipEventCreateWithFlags(&sl.ev_interior[i], hipEventDisableTiming));
   HIP_TRY(LBM_FAILURE, hipEventCreateWithFlags(&sl.ev_flush, hipEventDisableTiming));
   HIP_TRY(LBM_FAILURE, hipEventCreateWithFlags(&sl.ev_step, hipEventDisableTiming));
+  HIP_TRY(LBM_FAILURE, hipEventCreateWithFlags(&sl.ev_fork, hipEventDisableTiming));
   for (int i = 0; i < 2; i++) HIP_TRY(LBM_FAILURE, hipEventCreateWithFlags(&sl.ev_x[i], hipEventDisableTiming));
   HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_halo, sl.comm));
   HIP_TRY(LBM_FAILURE, hipEventCreate(&sl.ev_t0));
@@ -940,6 +1028,7 @@ int build_slab(lbm_ctx* c, int s, const ObstacleSource& obst, const float* cells
   HIP_TRY(LBM_FAILURE, hipMemsetAsync(sl.tot_u, 0, (size_t)(c->capacity > 0 ? c->capacity : 1) * sizeof(double), sl.compute));
   HIP_TRY(LBM_FAILURE, hipMalloc(&sl.scratch, 2 * kSumBlocks * sizeof(double)));
   HIP_TRY(LBM_FAILURE, hipMalloc(&sl.flushed_dev, sizeof(int)));
+  if (c->ranked) HIP_TRY(LBM_FAILURE, hipMalloc(&sl.reduce_buf, (size_t)(c->capacity > 0 ? c->capacity : 1) * sizeof(double)));
 
   // obstacle mask: uint8 (rows + 2*kMaskHalo) x pitch with the (periodic) neighbour rows beyond the slab, which a
   // multi-step pass relaxes redundantly.  Built on the device: from the reference's host type (int, SerialCode/
@@ -1246,7 +1335,6 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
     if (c->tile_steps < 0 || c->tile_steps > kTileShapes[c->tile_shape].kmax) c->tile_steps = kTileShapes[c->tile_shape].kmax;
     if (c->tile_steps && tile_count_for(params, c->tile_shape) > max_blocks) max_blocks = tile_count_for(params, c->tile_shape);
     // a graph chunk is kPartSlots timesteps in an even number of passes
-    if (c->tile_steps && (kPartSlots % c->tile_steps != 0 || (kPartSlots / c->tile_steps) % 2 != 0)) c->use_graph = 0;
   }
   c->part_stride = round_up(max_blocks, 64);
 
@@ -1301,7 +1389,23 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
   // With several slabs on ONE device it is slower (the runtime serialises calls to a device:
   // 65 vs 53 us per step for 2 slabs); whether it pays with one device per slab could not be
   // measured on the 1-GPU box.
-  if (n_slabs > 1 && env_int("LBM_THREADS", 0)) {
+  // One issuing thread per slab when one process drives several slabs on DISTINCT devices (LBM_GPUS=n on a multi-GPU
+  // node): a pass enqueues ~10 runtime calls per slab, 25-30 us on one thread -- more than an 8-GPU pass of 8192^2
+  // takes on the devices.  With several slabs on ONE device it is slower (the runtime serialises calls to a device:
+  // 65 vs 53 us per step for 2 slabs), so there it stays opt-in.  LBM_THREADS=0/1 overrides.
+  bool distinct_devices = n_slabs > 1;
+  for (int a = 0; a < n_slabs; a++)
+    for (int b = a + 1; b < n_slabs; b++)
+      if (c->slab[a].device == c->slab[b].device) distinct_devices = false;
+  const bool want_team = n_slabs > 1 && env_int("LBM_THREADS", distinct_devices ? 1 : 0);
+  // hipGraph replay of the halo pipeline (both streams of every slab, RCCL send/recv or device copies inside the
+  // capture) exists (capture_chunk) but is OFF unless LBM_GRAPH=1: measured on MI355X / ROCm 7.2 it buys nothing
+  // (host issue 11.1 vs 11.6 us per step for a rank with RCCL self-exchange at 256^2: the runtime still enqueues every
+  // node) and hipGraphInstantiate overflows its stack on the larger pipelines (3+ slabs with device-copy halos, a
+  // rank's 20-pass chunk at 8192x1024) -- profiles/r02_tuning.md.  The device-copy transport never uses it.
+  if (c->halo != HALO_SELF && (!getenv("LBM_GRAPH") || c->halo == HALO_MEMCPY)) c->use_graph = 0;
+  if (want_team) {
+    c->use_graph = 0;
     c->team = new SlabTeam();
     c->team->start(n_slabs);
   }
@@ -1427,7 +1531,11 @@ int lbm_get_info(const lbm_ctx* c, lbm_info* out) {
   out->band_rows = stream_kernel ? c->band_rows : 0;
   out->lane_cells = stream_kernel ? c->lane_cells : 0;
   out->nontemporal = c->nts;
-  out->graph_steps = (c->use_graph && c->halo == HALO_SELF) ? kPartSlots : 0;
+  {
+    int adv = 1;
+    const int passes = chunk_passes(c, &adv);
+    out->graph_steps = (c->use_graph && !stale) ? passes * adv : 0;
+  }
   return LBM_SUCCESS;
 }
 
@@ -1469,14 +1577,12 @@ int lbm_read_av_vels(lbm_ctx* c, float* out, int n) {
   if (c->ranked) {
     // the reference's MPI_Reduce(av_vels, SUM) (MPI/d2q9-bgk.c:298-309), as an all-reduce
     Slab& sl = c->slab[0];
-    double* tmp = nullptr;
+    double* tmp = sl.reduce_buf;  // allocated once at create: nothing to leak on an error return
     HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
-    HIP_TRY(LBM_FAILURE, hipMalloc(&tmp, (size_t)n * sizeof(double)));
     HIP_TRY(LBM_FAILURE, hipMemcpy(tmp, total.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
     NCCL_TRY(LBM_FAILURE, ncclAllReduce(tmp, tmp, (size_t)n, ncclDouble, ncclSum, sl.nccl, sl.comm));
     HIP_TRY(LBM_FAILURE, hipStreamSynchronize(sl.comm));
     HIP_TRY(LBM_FAILURE, hipMemcpy(total.data(), tmp, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-    HIP_TRY(LBM_FAILURE, hipFree(tmp));
   }
   const float cells = (float)c->fluid_cells;
   for (int t = 0; t < n; t++) out[t] = (float)total[(size_t)t] / cells;  // SerialCode/d2q9-bgk.c:457

@@ -48,21 +48,24 @@ int main(int argc, char* argv[])
   lbm_params params;
   lbm_read_params(paramfile, &params);
 
-  int* obstacles;
+  /* uniform equilibrium start is generated on the device (cells_aos == NULL); with LBM_TILE the mask is
+   * expanded on the device from the tile, and the global map is only built if final_state.dat is written
+   * (its last column is the obstacle flag, SerialCode/d2q9-bgk.c:722) */
+  int* obstacles = NULL;
   int tile_nx = 0, tile_ny = 0;
+  lbm_ctx* ctx;
   if ((env = getenv("LBM_TILE")) && sscanf(env, "%dx%d", &tile_nx, &tile_ny) == 2) {
     lbm_params tile_params = params;
     tile_params.nx = tile_nx;
     tile_params.ny = tile_ny;
     int* tile = lbm_read_obstacles(obstaclefile, &tile_params);
-    obstacles = lbm_tile_obstacles(tile, tile_nx, tile_ny, params.nx, params.ny);
+    ctx = lbm_create_tiled(&params, tile, tile_nx, tile_ny, NULL, n_gpus, math_mode);
+    if (write_text) obstacles = lbm_tile_obstacles(tile, tile_nx, tile_ny, params.nx, params.ny);
     free(tile);
   } else {
     obstacles = lbm_read_obstacles(obstaclefile, &params);
+    ctx = lbm_create(&params, obstacles, NULL, n_gpus, math_mode);
   }
-
-  /* uniform equilibrium start is generated on the device (cells_aos == NULL) */
-  lbm_ctx* ctx = lbm_create(&params, obstacles, NULL, n_gpus, math_mode);
   lbm_sync(ctx);
   const double init_toc = wall_seconds();
 
