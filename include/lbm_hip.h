@@ -99,6 +99,27 @@ int         lbm_device_count(void); /* visible HIP devices; 0 when none (never d
  */
 int lbm_partition_rows(int ny, int parts, int index, int* first, int* count);
 
+/*
+ * The halo exchange of one pass, as the engine posts it (host arithmetic only, no device): the reference's
+ * MPI_Isend x2 + MPI_Irecv x2 (MPI_Waitall/d2q9-bgk.c:225-230) with whole boundary rows, `depth` rows per side.
+ * out[0..3], in posting order: send my top rows to the north neighbour, send my bottom rows to the south
+ * neighbour, receive my south halo from the south neighbour, receive my north halo from the north neighbour
+ * (north = (index+1) % parts, south = (index-1+parts) % parts: the periodic ring of MPI/d2q9-bgk.c:210-211; with
+ * two parts both neighbours are the same peer and the first send pairs with that peer's first receive).
+ * row_first counts slab-local rows: 0 is the first owned row, negative rows are the south halo, rows >= `rows` the
+ * north halo.  lbm_plan_halo_depth: the depth (= timesteps per pass) the engine uses for a grid cut into `parts`
+ * row slabs with halos (environment overrides included); its own exchange is built from lbm_halo_plan, so a host
+ * that replays the protocol (tests/test_multirank_gloo.py) cannot drift from it.
+ */
+typedef struct {
+  int is_send;   /* 1: ncclSend / MPI_Isend, 0: ncclRecv / MPI_Irecv */
+  int peer;      /* neighbour's index in the ring */
+  int row_first; /* first slab-local row of the message */
+  int row_count; /* rows in the message (each row: 9 planes x pitch floats on the device) */
+} lbm_halo_op;
+int lbm_halo_plan(int rows, int parts, int index, int depth, lbm_halo_op out[4]);
+int lbm_plan_halo_depth(const lbm_params* params, int parts);
+
 /* ---- create / destroy --------------------------------------------------------------------
  * Replaces the buffer set-up half of initialise() (SerialCode/d2q9-bgk.c:531-567) and
  * finalise() (:615-634).

@@ -39,7 +39,7 @@ _HALO = {"sync": HALO_SYNC, "stale": HALO_STALE, HALO_SYNC: HALO_SYNC, HALO_STAL
 # every symbol include/lbm_hip.h declares (tests check the .so exports them all)
 ABI_SYMBOLS = (
     "lbm_set_error_mode", "lbm_last_error", "lbm_version", "lbm_device_count",
-    "lbm_partition_rows", "lbm_create", "lbm_rccl_unique_id", "lbm_create_rank", "lbm_create_rank_rows",
+    "lbm_partition_rows", "lbm_halo_plan", "lbm_plan_halo_depth", "lbm_create", "lbm_rccl_unique_id", "lbm_create_rank", "lbm_create_rank_rows",
     "lbm_create_tiled", "lbm_create_rank_tiled", "lbm_destroy",
     "lbm_get_info", "lbm_set_halo_mode", "lbm_run", "lbm_sync", "lbm_run_timed", "lbm_read_av_vels", "lbm_read_cells",
     "lbm_read_final_state", "lbm_av_velocity", "lbm_total_density", "lbm_calc_reynolds",
@@ -63,6 +63,11 @@ class _CInfo(ctypes.Structure):
                 ("world_size", ctypes.c_int), ("steps_per_launch", ctypes.c_int),
                 ("halo_mode", ctypes.c_int), ("band_rows", ctypes.c_int), ("lane_cells", ctypes.c_int),
                 ("nontemporal", ctypes.c_int), ("graph_steps", ctypes.c_int)]
+
+
+class _CHaloOp(ctypes.Structure):
+    _fields_ = [("is_send", ctypes.c_int), ("peer", ctypes.c_int), ("row_first", ctypes.c_int),
+                ("row_count", ctypes.c_int)]
 
 
 @dataclass
@@ -110,6 +115,8 @@ def load_library() -> ctypes.CDLL:
     lib.lbm_version.argtypes = []; lib.lbm_version.restype = ctypes.c_char_p
     lib.lbm_device_count.argtypes = []; lib.lbm_device_count.restype = I
     lib.lbm_partition_rows.argtypes = [I, I, I, PI, PI]; lib.lbm_partition_rows.restype = I
+    lib.lbm_halo_plan.argtypes = [I, I, I, I, ctypes.POINTER(_CHaloOp)]; lib.lbm_halo_plan.restype = I
+    lib.lbm_plan_halo_depth.argtypes = [ctypes.POINTER(_CParams), I]; lib.lbm_plan_halo_depth.restype = I
     lib.lbm_create.argtypes = [ctypes.POINTER(_CParams), P, P, I, I]; lib.lbm_create.restype = P
     lib.lbm_rccl_unique_id.argtypes = [P]; lib.lbm_rccl_unique_id.restype = I
     lib.lbm_create_rank.argtypes = [ctypes.POINTER(_CParams), P, P, I, I, P, I, I]
@@ -153,6 +160,25 @@ def partition_rows(ny: int, parts: int, index: int) -> tuple[int, int]:
     first, count = ctypes.c_int(), ctypes.c_int()
     _check(lib, lib.lbm_partition_rows(ny, parts, index, ctypes.byref(first), ctypes.byref(count)))
     return first.value, count.value
+
+
+def halo_plan(rows: int, parts: int, index: int, depth: int) -> list[dict]:
+    """The four halo messages of one pass in the engine's posting order (lbm_halo_plan)."""
+    lib = load_library()
+    ops = (_CHaloOp * 4)()
+    _check(lib, lib.lbm_halo_plan(rows, parts, index, depth, ops))
+    return [{"is_send": bool(o.is_send), "peer": o.peer, "row_first": o.row_first, "row_count": o.row_count}
+            for o in ops]
+
+
+def plan_halo_depth(params: "Params", parts: int) -> int:
+    """Halo depth = timesteps per pass the engine uses for `parts` row slabs (lbm_plan_halo_depth)."""
+    lib = load_library()
+    cp = params._c()
+    d = lib.lbm_plan_halo_depth(ctypes.byref(cp), parts)
+    if d <= 0:
+        raise LbmError(lib.lbm_last_error().decode())
+    return int(d)
 
 
 def rccl_unique_id() -> bytes:

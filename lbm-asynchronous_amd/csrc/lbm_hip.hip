@@ -484,16 +484,22 @@ int exchange_halos(lbm_ctx* c, int depth, int src, int dst, int slot) {
       float* to = sl.lat[dst];
       int me, parts;
       if (c->ranked) { me = c->rank; parts = c->world; } else { me = s; parts = c->n_slabs; }
-      const int north = (me + 1) % parts, south = (me - 1 + parts) % parts;
       if (c->team) {
         HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
         NCCL_TRY(LBM_FAILURE, ncclGroupStart());
       }
-      // order matters when north == south (2 parts): first send pairs with the peer's first recv
-      NCCL_TRY(LBM_FAILURE, ncclSend(from + (long)(sl.rows - depth) * c->row_pitch, n, ncclFloat, north, sl.nccl, sl.comm));
-      NCCL_TRY(LBM_FAILURE, ncclSend(from, n, ncclFloat, south, sl.nccl, sl.comm));
-      NCCL_TRY(LBM_FAILURE, ncclRecv(to - n, n, ncclFloat, south, sl.nccl, sl.comm));
-      NCCL_TRY(LBM_FAILURE, ncclRecv(to + (long)sl.rows * c->row_pitch, n, ncclFloat, north, sl.nccl, sl.comm));
+      // the four operations in the posting order of lbm_halo_plan (the order matters when north == south, 2 parts:
+      // the first send pairs with the peer's first receive)
+      lbm_halo_op ops[4];
+      if (lbm_halo_plan(sl.rows, parts, me, depth, ops) != LBM_SUCCESS) return LBM_FAILURE;
+      for (int i = 0; i < 4; i++) {
+        if (ops[i].is_send)
+          NCCL_TRY(LBM_FAILURE, ncclSend(from + (long)ops[i].row_first * c->row_pitch, (size_t)ops[i].row_count * c->row_pitch,
+                                         ncclFloat, ops[i].peer, sl.nccl, sl.comm));
+        else
+          NCCL_TRY(LBM_FAILURE, ncclRecv(to + (long)ops[i].row_first * c->row_pitch, (size_t)ops[i].row_count * c->row_pitch,
+                                         ncclFloat, ops[i].peer, sl.nccl, sl.comm));
+      }
       if (c->team) NCCL_TRY(LBM_FAILURE, ncclGroupEnd());
       return LBM_SUCCESS;
     });
@@ -1121,6 +1127,38 @@ int build_slab(lbm_ctx* c, int s, const ObstacleSource& obst, const float* cells
   return LBM_SUCCESS;
 }
 
+// Which step kernel advances a decomposition of the grid into `parts` row slabs (in one process or over ranks), and how
+// many timesteps it takes per pass -- from global numbers only, so every rank of a multi-process run decides alike.
+// create_common and the host-only query lbm_plan_halo_depth share it.
+struct StreamPlan { bool vec4; int fuse2, lane_cells, pass_steps; };
+StreamPlan plan_stream(const lbm_params* params, int parts, bool halo_on) {
+  StreamPlan pl;
+  // 4 cells per lane need nx % 4 == 0; tiny single-slab grids are latency-bound and run faster with one
+  // cell per lane (4x the waves, a quarter of the dependent arithmetic per lane: 128^2 3.2 vs 5.0 us per
+  // step, 256^2 3.8 vs 5.2; from 512^2 on the 4-cell kernel wins).  Asking for the stream kernel,
+  // which exists in the 4- and 2-cell forms only, implies vec4; so do halos.
+  pl.vec4 = (params->nx % 4 == 0) &&
+            env_int("LBM_VEC4", ((long)params->nx * params->ny >= 128L * 1024 || env_int("LBM_FUSE2", 0) == 1 || halo_on) ? 1 : 0);
+  const int min_rows = params->ny / (parts > 0 ? parts : 1);  // the thinnest slab of a balanced partition
+  const long min_cells = (long)params->nx * min_rows;
+  // Across slabs / ranks a pass costs one exchange and ~10 runtime calls per slab whatever it computes, so
+  // several timesteps per pass always pay there (1024^2 over 2/4/8 slabs on one device: 45/74/97 us per step
+  // vs 70/113/125 one-step; 2048^2 over 8: 96 vs 261).
+  pl.fuse2 = (pl.vec4 && env_int("LBM_FUSE2", (min_cells >= 560L * 1024 || halo_on) ? 1 : 0)) ? 1 : 0;
+  pl.lane_cells = env_int("LBM_LANE_CELLS", min_cells >= 3L * 1024 * 1024 ? 4 : 2) == 2 ? 2 : 4;
+  // Timesteps per pass of the stream kernel.  The two-step kernel at 8192^2 is bound by DRAM traffic (round-2 PMC),
+  // so the 4-cell form runs THREE steps per pass (stepk_stream<K = 3>: 198-239 VGPRs, 2 waves per SIMD, the next
+  // row prefetched): 8192^2 0.345-0.353 vs 0.466-0.491 ms per step, 16384^2 1.39 vs 2.23, 4096^2 0.103 vs 0.134.
+  // K = 4 (245 VGPRs) is bound by VALU issue and slower (0.361).  The 2-cell form exists for K = 2 only.
+  pl.pass_steps = env_int("LBM_PASS_STEPS", pl.lane_cells == 4 ? 3 : 2);
+  if (pl.pass_steps < 2 || pl.pass_steps > kHaloRows || pl.lane_cells != 4) pl.pass_steps = 2;
+  // across slabs a K-step pass needs slabs of at least 2K rows (the stream kernel at all: 4); a periodic slab at least K
+  if (halo_on && min_rows < 2 * pl.pass_steps) pl.pass_steps = 2;
+  if (halo_on && min_rows < 4) pl.fuse2 = 0;
+  if (min_rows < pl.pass_steps) pl.pass_steps = 2;
+  return pl;
+}
+
 lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, const float* cells_aos,
                        int n_slabs, int math_mode, int rank, int world, const void* unique_id,
                        int device) {
@@ -1177,13 +1215,9 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
     if (hm && !strcmp(hm, "stale")) c->halo_mode = LBM_HALO_STALE;
   }
 
-  // 4 cells per lane need nx % 4 == 0; tiny single-slab grids are latency-bound and run faster with one
-  // cell per lane (4x the waves, a quarter of the dependent arithmetic per lane: 128^2 3.2 vs 5.0 us per
-  // step, 256^2 3.8 vs 5.2; from 512^2 on the 4-cell kernel wins).  Asking for the two-step kernel,
-  // which exists in the 4- and 2-cell forms only, implies vec4; so do halos (see below).
   const bool halo_on = (c->halo != HALO_SELF);
-  c->vec4 = (params->nx % 4 == 0) &&
-            env_int("LBM_VEC4", ((long)params->nx * params->ny >= 128L * 1024 || env_int("LBM_FUSE2", 0) == 1 || halo_on) ? 1 : 0);
+  const StreamPlan plan = plan_stream(params, world * n_slabs, halo_on);
+  c->vec4 = plan.vec4;
 
   int max_blocks = 0;
   for (int s = 0; s < n_slabs; s++) {
@@ -1236,22 +1270,10 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
   //                        2560^2 41.8 | 62.4 | 59.4, 3072^2 59.0 | 76.0 | 90.5, 4096^2 93 | 129, 8192^2 340 | 492)
   // LBM_FUSE2, LBM_LANE_CELLS, LBM_BAND_ROWS override.  Ranks decide from global numbers only, so
   // every rank of a multi-process run takes the same path.
-  long min_cells = (long)params->nx * params->ny;
-  for (int s = 0; s < n_slabs; s++)
-    if ((long)params->nx * c->slab[s].rows < min_cells) min_cells = (long)params->nx * c->slab[s].rows;
-  if (world > 1) min_cells = (long)params->nx * (params->ny / world);
-  // Across slabs / ranks a pass costs one exchange and ~10 runtime calls per slab whatever it computes, so
-  // two timesteps per pass always pay there (1024^2 over 2/4/8 slabs on one device: 45/74/97 us per step
-  // vs 70/113/125 one-step; 2048^2 over 8: 96 vs 261).
-  c->fuse2 = (c->vec4 && env_int("LBM_FUSE2", (min_cells >= 560L * 1024 || halo_on) ? 1 : 0)) ? 1 : 0;
-  c->lane_cells = env_int("LBM_LANE_CELLS", min_cells >= 3L * 1024 * 1024 ? 4 : 2) == 2 ? 2 : 4;
+  c->fuse2 = plan.fuse2;
+  c->lane_cells = plan.lane_cells;
   c->n_strips = ceil_div(params->nx / c->lane_cells > 0 ? params->nx / c->lane_cells : 1, lbm::kStripQuads);
-  // Timesteps per pass of the stream kernel.  The two-step kernel at 8192^2 is bound by DRAM traffic (round-2 PMC),
-  // so the 4-cell form runs THREE steps per pass (stepk_stream<K = 3>: 198-239 VGPRs, 2 waves per SIMD, the next
-  // row prefetched): 8192^2 0.345-0.353 vs 0.466-0.491 ms per step, 16384^2 1.39 vs 2.23, 4096^2 0.103 vs 0.134.
-  // K = 4 (245 VGPRs) is bound by VALU issue and slower (0.361).  The 2-cell form exists for K = 2 only.
-  c->pass_steps = env_int("LBM_PASS_STEPS", c->lane_cells == 4 ? 3 : 2);
-  if (c->pass_steps < 2 || c->pass_steps > kHaloRows || c->lane_cells != 4) c->pass_steps = 2;
+  c->pass_steps = plan.pass_steps;
   c->prefetch = env_int("LBM_PREFETCH", c->pass_steps == 3 ? 1 : 0) ? 1 : 0;  // K = 4 + prefetch spills
   // strips per XCD chunk: half a row of strips, for slabs of many rounds of waves only (12288^2 0.793 vs 0.832 ms per
   // step, 16384^2 1.369 vs 1.381).  Elsewhere the band height packs the waves tightly into rounds (below) and the
@@ -1309,15 +1331,9 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
   }
   if (c->band_rows < 1) c->band_rows = 1;
   for (int s = 0; s < n_slabs; s++) {
-    // across slabs a K-step pass needs slabs of at least 2K rows; a periodic slab at least K
-    if (c->halo != HALO_SELF && c->slab[s].rows < 2 * c->pass_steps) c->pass_steps = 2;
-    if (c->halo != HALO_SELF && c->slab[s].rows < 4) c->fuse2 = 0;
-    if (c->slab[s].rows < c->pass_steps) c->pass_steps = 2;
     const int waves = c->n_strips * (ceil_div(c->slab[s].rows, c->band_rows) + 2);
     if (c->fuse2 && waves > max_blocks) max_blocks = waves;
   }
-  if (world > 1 && params->ny / world < 2 * c->pass_steps) c->pass_steps = 2;
-  if (world > 1 && params->ny / world < 4) c->fuse2 = 0;
   // LDS-tile kernel (several timesteps per launch) for small single-slab grids: LBM_TILE_STEPS overrides
   if (!halo_on) {
     // measured (us per step; one-step kernels | 16x8 tiles, 4 steps per launch | 32x16 tiles, 3 steps per launch):
@@ -1440,6 +1456,24 @@ int lbm_partition_rows(int ny, int parts, int index, int* first, int* count) {
   if (first) *first = fst;
   if (count) *count = cnt;
   return LBM_SUCCESS;
+}
+
+int lbm_halo_plan(int rows, int parts, int index, int depth, lbm_halo_op out[4]) {
+  if (!out || rows < 1 || parts < 1 || index < 0 || index >= parts || depth < 1 || depth > rows)
+    LBM_FAIL(LBM_FAILURE, "lbm_halo_plan: bad arguments (rows=%d parts=%d index=%d depth=%d)", rows, parts, index, depth);
+  // ring with periodic wrap (MPI/d2q9-bgk.c:210-211): north = the part above, south = the part below
+  const int north = (index + 1) % parts, south = (index - 1 + parts) % parts;
+  out[0] = {1, north, rows - depth, depth};  // my top rows     -> north's rows [-depth, 0)
+  out[1] = {1, south, 0, depth};             // my bottom rows  -> south's rows [rows_s, rows_s + depth)
+  out[2] = {0, south, -depth, depth};        // my south halo  <-  south's top rows
+  out[3] = {0, north, rows, depth};          // my north halo  <-  north's bottom rows
+  return LBM_SUCCESS;
+}
+
+int lbm_plan_halo_depth(const lbm_params* params, int parts) {
+  if (!validate_params(params) || parts < 1) LBM_FAIL(0, "lbm_plan_halo_depth: bad arguments");
+  const StreamPlan pl = plan_stream(params, parts, true);
+  return pl.fuse2 ? pl.pass_steps : 1;
 }
 
 lbm_ctx* lbm_create(const lbm_params* params, const int* obstacles, const float* cells_aos,

@@ -95,3 +95,43 @@ def test_die_mode_matches_reference_message_shape(lbm):
     assert out.returncode == 1
     assert "survived" not in out.stdout
     assert re.search(r"^Error at line \d+ of file .*:\n.*fewer than 2 rows", out.stderr, flags=re.M)
+
+
+def test_halo_plan_pairs_up_around_the_ring(lbm):
+    """lbm_halo_plan (host-only): every send has exactly one matching receive on the peer, in the same position of
+    the peer's posting order when both neighbours are the same peer (two parts) -- the property RCCL / MPI rely on."""
+    for parts in (1, 2, 3, 8):
+        rows = [lbm.partition_rows(64, parts, i)[1] for i in range(parts)]
+        for depth in (1, 2, 3):
+            plans = [lbm.halo_plan(rows[i], parts, i, depth) for i in range(parts)]
+            for i, plan in enumerate(plans):
+                assert [op["is_send"] for op in plan] == [True, True, False, False]
+                n, s_ = (i + 1) % parts, (i - 1) % parts
+                assert [op["peer"] for op in plan] == [n, s_, s_, n]
+                assert plan[0]["row_first"] == rows[i] - depth and plan[1]["row_first"] == 0
+                assert plan[2]["row_first"] == -depth and plan[3]["row_first"] == rows[i]
+                assert all(op["row_count"] == depth for op in plan)
+                # k-th send to peer q pairs with the k-th receive q posts from me
+                for q in set(op["peer"] for op in plan):
+                    sends = [op for op in plan if op["is_send"] and op["peer"] == q]
+                    recvs = [op for op in plans[q] if not op["is_send"] and op["peer"] == i]
+                    assert len(sends) == len(recvs)
+                    for a, b in zip(sends, recvs):
+                        # my top rows land in the peer's south halo, my bottom rows in its north halo
+                        assert (a["row_first"] == 0) == (b["row_first"] == rows[q])
+    with pytest.raises(lbm.LbmError):
+        lbm.halo_plan(4, 2, 0, 5)          # deeper than the slab
+
+
+def test_plan_halo_depth_follows_the_kernel_policy(lbm, monkeypatch):
+    for k in ("LBM_FUSE2", "LBM_LANE_CELLS", "LBM_PASS_STEPS", "LBM_VEC4"):
+        monkeypatch.delenv(k, raising=False)
+    small = lbm.Params(128, 256, 10, 10, 0.1, 0.005, 1.85)
+    big = lbm.Params(8192, 8192, 10, 10, 0.1, 0.01, 1.85)
+    ragged = lbm.Params(130, 64, 10, 10, 0.1, 0.005, 1.85)
+    assert lbm.plan_halo_depth(small, 2) == 2          # two-step kernel, 2 cells per lane
+    assert lbm.plan_halo_depth(big, 8) == 3            # 8192x1024 per rank: three-step kernel
+    assert lbm.plan_halo_depth(big, 2) == 3
+    assert lbm.plan_halo_depth(ragged, 2) == 1         # nx % 4 != 0: one step per pass
+    monkeypatch.setenv("LBM_PASS_STEPS", "2")
+    assert lbm.plan_halo_depth(big, 8) == 2

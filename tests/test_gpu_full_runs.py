@@ -16,7 +16,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -131,10 +131,9 @@ def big_case(lbm):
     return p, ob
 
 
-def test_8192_short_run_bitwise_vs_oracle(lbm, oracle, big_case):
-    """BASELINE.json config 3 (synthetic 8192x8192, 1024x1024 obstacles tiled 8x8): 50 steps (the
-    parity run SURVEY.md section 8d asks for) against the oracle's multi-threaded fused form; lattice and pressure bit-identical, av_vels by the
-    check.py rule (big-grid parity through binary fields, not text files)."""
+@pytest.fixture(scope="module")
+def big_oracle_50(oracle, big_case):
+    """50 steps of the 8192x8192 case on the CPU oracle (multi-threaded fused form): planes, av_vels."""
     p, ob = big_case
     steps = 50
     src = np.empty((9, p.ny, p.nx), dtype=np.float32)
@@ -149,21 +148,60 @@ def test_8192_short_run_bitwise_vs_oracle(lbm, oracle, big_case):
         ref_av.append(np.float32(oracle.fused_step_periodic(p, src, dst, ob)) / fluid)
         src, dst = dst, src
     del dst
-    with lbm.Engine(p, ob, None) as eng:
+    return steps, src, np.array(ref_av, dtype=np.float32)
+
+
+@pytest.mark.parametrize("slabs", [1, 8])
+def test_8192_short_run_bitwise_vs_oracle(lbm, big_case, big_oracle_50, monkeypatch, slabs):
+    """BASELINE.json config 3 (synthetic 8192x8192, 1024x1024 obstacles tiled 8x8): 50 steps (the parity run
+    SURVEY.md section 8d asks for) against the oracle's multi-threaded fused form; lattice and pressure
+    bit-identical, av_vels by the check.py rule (big-grid parity through binary fields, not text files).
+    slabs = 8: the same workload cut into the 8 row slabs config 4 gives its ranks (1024 rows each; here sharing
+    the device, halos by device copies -- RCCL cannot open 8 communicators on one device): three-step passes,
+    3-row halos, interior / boundary pipeline; 50 = 16 three-step passes + one two-step pass."""
+    p, ob = big_case
+    steps, src, ref_av = big_oracle_50
+    monkeypatch.setenv("LBM_HALO", "memcpy")
+    with lbm.Engine(p, ob, None, n_gpus=slabs) as eng:
+        info = eng.info()
+        assert info["n_slabs"] == slabs and info["steps_per_launch"] == 3
         eng.run(steps)
         got_av = eng.av_vels(steps)
         got = eng.cells()                      # (ny, nx, 9)
         fields = eng.final_state()
     for k in range(9):
         assert np.array_equal(got[:, :, k].view(np.uint32), src[k].view(np.uint32)), f"speed {k}"
-    assert lbm.check_passes(np.array(ref_av), got_av)
-    np.testing.assert_allclose(got_av, np.array(ref_av, dtype=np.float32), rtol=2e-3)
+    assert lbm.check_passes(ref_av, got_av)
+    np.testing.assert_allclose(got_av, ref_av, rtol=2e-3)
     rho = src[0].copy()
     for k in range(1, 9):
         rho += src[k]                          # same left-to-right fp32 order as the reference
     want_p = np.where(ob == 1, np.float32(p.density) * np.float32(1.0 / 3.0), rho * np.float32(1.0 / 3.0))
     assert np.array_equal(fields["pressure"].view(np.uint32), want_p.astype(np.float32).view(np.uint32))
     assert not fields["u"][ob == 1].any()
+
+
+def test_bench_rank_pipeline_checks_itself(lbm):
+    """bench.py through the one-process-per-GPU code path on the 1-GPU box (world of one: lbm_create_rank_tiled,
+    RCCL self-exchange, interior / boundary split): exactly one JSON line on stdout, whose multi_gpu_check says the
+    rank's fields are bit-identical to a plain single-GPU run of the same workload."""
+    import json
+    import sys
+    env = dict(os.environ, LBM_BENCH_RANK_API="1", LBM_FORCE_HALO="1", LBM_BENCH_ALSO="0", LBM_BENCH_REPEATS="2",
+               LBM_BENCH_PREWARM_S="0.05")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--grid", "4096x2048", "--steps", "31",
+                          "--warmup", "5", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["steps"] == 31 and rec["results_finite"] is True
+    assert rec["multi_gpu_check"]["fields_bitwise_equal_to_single_gpu_run"] is True
+    assert rec["multi_gpu_check"]["av_vels_max_rel_diff"] < 5e-5
+    assert 0.0 < rec["roofline"]["frac"] <= 1.0 and rec["roofline"]["steps_per_launch"] == 3
+    assert len(rec["timing"]["repeats_ms_per_step"]) == 2
 
 
 def test_cli_8192_tiled_run_against_oracle_cli(lbm, oracle, tmp_path):

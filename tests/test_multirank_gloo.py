@@ -1,20 +1,20 @@
 """N > 1 path on CPU: world_size 2 and 3 over torch.distributed/gloo.
 
-The GPU engine shards the grid by rows, one slab per rank, keeps two halo rows around every slab
+The GPU engine shards the grid by rows, one slab per rank, keeps halo rows around every slab
 and, once per pass, ships WHOLE boundary rows to its ring neighbours (lbm_hip.hip: exchange_halos --
-the GPU analogue of /root/reference/MPI_Waitall/d2q9-bgk.c:225-253); a pass advances TWO timesteps
-when the two-step kernel is active (halo depth 2), else one.  RCCL needs one GPU per rank, which
-the builder container and the 1-GPU box lack, so this test replays the SAME protocol on CPU ranks:
+the GPU analogue of /root/reference/MPI_Waitall/d2q9-bgk.c:225-253); a pass advances K timesteps
+(K = 2 or 3: the stream kernels, halo depth K), else one.  RCCL needs one GPU per rank, which
+the builder container and the 1-GPU box lack, so this test replays the SAME protocol on CPU ranks,
+with the bookkeeping taken from the product so the replay cannot drift from the engine:
 
-  * rows from the product's own lbm_partition_rows (C ABI, host-only call);
-  * per pass: my top `depth` rows -> rank+1's south halo, my bottom `depth` rows -> rank-1's north
-    halo, posted in the engine's order (send N, send S, recv S, recv N), which must pair correctly
-    when rank+1 == rank-1 (world_size 2);
+  * rows from the product's own lbm_partition_rows, K from lbm_plan_halo_depth, and the four messages
+    of an exchange (peer, rows, posting order) from lbm_halo_plan -- the C-ABI, host-only functions
+    exchange_halos itself is built on; the order must pair correctly when rank+1 == rank-1 (world_size 2);
   * rows that touch no halo first, the rest after the halos arrived (the Waitall pattern);
-  * two-step pass: step t is relaxed on rows -1..rows (the two halo-adjacent rows redundantly,
-    exactly as the neighbour relaxes them), step t+1 on the owned rows; the lid row (global ny-2)
+  * K-step pass: step t+j-1 is relaxed on rows -(K-j)..rows-1+(K-j) (the halo-adjacent rows redundantly,
+    exactly as the neighbour relaxes them), the last step on the owned rows; the lid row (global ny-2)
     is accelerated wherever a rank holds a copy of it, owned or halo;
-  * an odd step count ends with a one-step pass (which reads only the inner halo row);
+  * a step count that is not a multiple of K ends with a two-step and / or a one-step pass;
   * per-step partial sums of |u| over OWNED rows all-reduced at the end
     (MPI/d2q9-bgk.c:298-309) and divided by the global fluid-cell count; rows gathered on rank 0
     (MPI/d2q9-bgk.c:265-295).
@@ -48,9 +48,10 @@ def free_port():
         return s.getsockname()[1]
 
 
-def rank_main(rank, world, port, name, steps, out_dir, lag=0, seed=None):
+def rank_main(rank, world, port, name, steps, out_dir, lag=0, seed=None, env=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.update(env or {})
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import conftest
@@ -58,89 +59,101 @@ def rank_main(rank, world, port, name, steps, out_dir, lag=0, seed=None):
         lbm = conftest.load_package()
         oracle = oracle_binding.load()
         p, ob = conftest.dataset(name)
+        # the decomposition, the halo depth (= timesteps per pass) and the four messages of an exchange all come
+        # from the product's host-only C-ABI queries -- the very functions its own exchange_halos is built on
         first, rows = lbm.partition_rows(p.ny, world, rank)
-        north, south = (rank + 1) % world, (rank - 1 + world) % world
-        H = 2                                                  # halo rows kept around the slab
-        # local index (-1 .. rows) of the lid row if this rank holds a copy of it, else None
-        lid_local = None
-        for shift in (-p.ny, 0, p.ny):
-            loc = p.ny - 2 + shift - first
-            if -1 <= loc <= rows:
-                lid_local = loc
+        K = lbm.plan_halo_depth(p, world)
+        H = K + 1                                              # halo rows kept around the slab
+        M = max(K - 1, 1)                                      # halo rows a K-step pass may relax redundantly
+        # local indices of the copies of the lid row this rank holds (owned or among the relaxed halo rows)
+        lid_rows = [p.ny - 2 + shift - first for shift in (-p.ny, 0, p.ny)
+                    if -M <= p.ny - 2 + shift - first < rows + M]
 
         start = oracle.init_cells(p) if seed is None else random_cells(p, seed)
         full = np.ascontiguousarray(start.transpose(2, 0, 1))                     # (9, ny, nx)
-        S = np.zeros((9, rows + 2 * H, p.nx), dtype=np.float32)                   # array row = local row + H
-        S[:, H:H + rows] = full[:, first:first + rows]
-        T = np.zeros_like(S)
-        U = np.zeros_like(S)
-        # mask of local rows -1 .. rows (periodic neighbours), as the engine uploads it
-        mask = np.ascontiguousarray(ob[[(first + r) % p.ny for r in range(-1, rows + 1)]])
+        bufs = [np.zeros((9, rows + 2 * H, p.nx), dtype=np.float32) for _ in range(K + 1)]   # array row = local row + H
+        bufs[0][:, H:H + rows] = full[:, first:first + rows]
+        # mask of local rows -(H-1) .. rows+H-2 (periodic neighbours), as the engine builds it
+        mask = np.ascontiguousarray(ob[[(first + r) % p.ny for r in range(-(H - 1), rows + H - 1)]])
         tot_u = np.zeros(steps, dtype=np.float64)
         ps = (rows + 2 * H) * p.nx
 
         def accelerate(arr, local_row):
             oracle.lib.lbm_oracle_accelerate_row_soa(p.nx, p.density, p.accel, arr.ctypes.data, ps,
-                                                     mask[local_row + 1].ctypes.data, local_row + H)
+                                                     mask[local_row + H - 1].ctypes.data, local_row + H)
 
         def relax(src, dst, lo, hi):
             """advance local rows lo..hi (inclusive) of src into dst; returns sum |u| of those rows"""
             if hi < lo:
                 return 0.0
-            return oracle.fused_rows(p.nx, rows + 2, p.density, p.accel, p.omega, src, dst, mask, 0,
+            return oracle.fused_rows(p.nx, rows + 2 * (H - 1), p.density, p.accel, p.omega, src, dst, mask, 0,
                                      lo + H, hi + H)
 
         def exchange(arr, depth):
-            send_n = torch.from_numpy(np.ascontiguousarray(arr[:, H + rows - depth:H + rows]))
-            send_s = torch.from_numpy(np.ascontiguousarray(arr[:, H:H + depth]))
-            recv_s, recv_n = torch.empty_like(send_n), torch.empty_like(send_s)
-            # the engine's posting order: send N, send S, recv S, recv N
-            ops = [dist.P2POp(dist.isend, send_n, north), dist.P2POp(dist.isend, send_s, south),
-                   dist.P2POp(dist.irecv, recv_s, south), dist.P2POp(dist.irecv, recv_n, north)]
-            return dist.batch_isend_irecv(ops), recv_s, recv_n
+            """post the engine's four messages in the engine's order; returns the requests and where receives land"""
+            ops, landing = [], []
+            for op in lbm.halo_plan(rows, world, rank, depth):
+                lo = op["row_first"] + H
+                if op["is_send"]:
+                    t = torch.from_numpy(np.ascontiguousarray(arr[:, lo:lo + op["row_count"]]))
+                    ops.append(dist.P2POp(dist.isend, t, op["peer"]))
+                else:
+                    t = torch.empty((9, op["row_count"], p.nx), dtype=torch.float32)
+                    ops.append(dist.P2POp(dist.irecv, t, op["peer"]))
+                    landing.append((lo, op["row_count"], t))
+            return dist.batch_isend_irecv(ops), landing
 
-        def land(arr, depth, recv_s, recv_n):
-            arr[:, H - depth:H] = recv_s.numpy()
-            arr[:, H + rows:H + rows + depth] = recv_n.numpy()
+        def land(arr, landing):
+            for lo, n, t in landing:
+                arr[:, lo:lo + n] = t.numpy()
 
         t, m, stale = 0, 0, None
+        S = bufs[0]
         while t < steps:
-            two = t + 1 < steps and not lag      # stale passes always advance one timestep
-            depth = 2          # the engine ships both halo rows every pass once the two-step kernel is on
+            left = steps - t
+            # the engine's pass: K timesteps while that many remain, then two, then one; stale passes advance one
+            k = 1 if lag else (K if left >= K else (2 if left >= 2 else 1))
+            depth = 1 if lag else K          # the engine ships K halo rows every pass once the stream kernel is on
             # accelerate_flow of step t on the owned copy; the halo copies arrive already accelerated
-            if lid_local is not None and 0 <= lid_local < rows:
-                accelerate(S, lid_local)
-            reqs, recv_s, recv_n = exchange(S, depth)
+            for r in lid_rows:
+                if 0 <= r < rows:
+                    accelerate(S, r)
+            reqs, landing = exchange(S, depth)
             if lag and m > 0:
                 # stale-halo mode (run_steps_stale): this pass reads what the neighbours sent one pass
                 # ago; the exchange posted above only has to land before the NEXT pass
-                land(S, depth, *stale)
+                land(S, stale)
+            others = [b for b in bufs if b is not S]
+            T = others[0]
             # step t on the rows whose inputs are all owned (overlaps the exchange) ...
-            s_in = relax(S, T, 1, rows - 2)
+            s_in = relax(S, T, k, rows - 1 - k)
             for r in reqs:
                 r.wait()
             if lag:
                 if m == 0:
-                    land(S, depth, recv_s, recv_n)              # every run starts from fresh halos
-                stale = (recv_s.clone(), recv_n.clone())
+                    land(S, landing)                            # every run starts from fresh halos
+                stale = [(lo, n, tt.clone()) for lo, n, tt in landing]
             else:
-                land(S, depth, recv_s, recv_n)
-            if two:
-                # ... then on rows -1, 0 and rows-1, rows (halo-dependent; -1 and rows redundantly)
-                relax(S, T, -1, -1)
-                s_b = relax(S, T, 0, 0) + relax(S, T, rows - 1, rows - 1)
-                relax(S, T, rows, rows)
-                tot_u[t] = float(s_in) + float(s_b)
-                # accelerate_flow of step t+1 on every copy of the lid row this rank holds
-                if lid_local is not None:
-                    accelerate(T, lid_local)
-                tot_u[t + 1] = float(relax(T, U, 0, rows - 1))
-                S, U = U, S
-                t += 2
-            else:
-                tot_u[t] = float(s_in) + float(relax(S, T, 0, 0)) + float(relax(S, T, rows - 1, rows - 1))
-                S, T = T, S
-                t += 1
+                land(S, landing)
+            # ... then on the halo-dependent rows: owned rows [0, k) and [rows-k, rows), and (k > 1) the k-1 halo
+            # rows on each side, relaxed redundantly exactly as their owners relax them
+            s_b = relax(S, T, 0, k - 1) + relax(S, T, rows - k, rows - 1)
+            relax(S, T, -(k - 1), -1)
+            relax(S, T, rows, rows + k - 2)
+            tot_u[t] = float(s_in) + float(s_b)
+            cur = T
+            for j in range(2, k + 1):
+                # accelerate_flow of step t+j-1 on every copy of the lid row this rank holds
+                for r in lid_rows:
+                    if -(k - j + 1) <= r <= rows - 1 + (k - j + 1):
+                        accelerate(cur, r)
+                nxt = others[j - 1]
+                relax(cur, nxt, -(k - j), -1)
+                tot_u[t + j - 1] = float(relax(cur, nxt, 0, rows - 1))
+                relax(cur, nxt, rows, rows + (k - j) - 1)
+                cur = nxt
+            S = cur
+            t += k
             m += 1
 
         tot = torch.from_numpy(tot_u)
@@ -157,16 +170,23 @@ def rank_main(rank, world, port, name, steps, out_dir, lag=0, seed=None):
                 result[:, f:f + n] = buf.numpy()
             np.save(os.path.join(out_dir, "lattice.npy"), result)
             np.save(os.path.join(out_dir, "av.npy"), av)
+            np.save(os.path.join(out_dir, "depth.npy"), np.array([K]))
         else:
             dist.send(mine, dst=0)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,name,steps", [(2, "128x128", 61), (3, "128x256", 40)])
-def test_row_sharded_ring_equals_single_domain(tmp_path, oracle, datasets, lbm, world, name, steps):
+THREE_STEP = {"LBM_FUSE2": "1", "LBM_LANE_CELLS": "4", "LBM_PASS_STEPS": "3"}   # what slabs of >= 3 Mi cells get
+
+
+@pytest.mark.parametrize("world,name,steps,env,depth", [(2, "128x128", 61, None, 2), (3, "128x256", 40, None, 2),
+                                                        (2, "128x128", 62, THREE_STEP, 3), (3, "128x256", 43, THREE_STEP, 3),
+                                                        (4, "128x256", 31, THREE_STEP, 3)])
+def test_row_sharded_ring_equals_single_domain(tmp_path, oracle, datasets, lbm, world, name, steps, env, depth):
     torch.set_num_threads(1)
-    mp.spawn(rank_main, args=(world, free_port(), name, steps, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(rank_main, args=(world, free_port(), name, steps, str(tmp_path), 0, None, env), nprocs=world, join=True)
+    assert int(np.load(tmp_path / "depth.npy")[0]) == depth
     p, ob = datasets(name)
     ref = oracle.init_cells(p)
     ref_av = oracle.run(p, ref, ob, steps)
