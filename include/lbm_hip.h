@@ -108,7 +108,7 @@ int lbm_partition_rows(int ny, int parts, int index, int* first, int* count);
  * two parts both neighbours are the same peer and the first send pairs with that peer's first receive).
  * row_first counts slab-local rows: 0 is the first owned row, negative rows are the south halo, rows >= `rows` the
  * north halo.  lbm_plan_halo_depth: the depth (= timesteps per pass) the engine uses for a grid cut into `parts`
- * row slabs with halos (environment overrides included); its own exchange is built from lbm_halo_plan, so a host
+ * row slabs with halos in the given math mode (environment overrides included); its own exchange is built from lbm_halo_plan, so a host
  * that replays the protocol (tests/test_multirank_gloo.py) cannot drift from it.
  */
 typedef struct {
@@ -118,7 +118,7 @@ typedef struct {
   int row_count; /* rows in the message (each row: 9 planes x pitch floats on the device) */
 } lbm_halo_op;
 int lbm_halo_plan(int rows, int parts, int index, int depth, lbm_halo_op out[4]);
-int lbm_plan_halo_depth(const lbm_params* params, int parts);
+int lbm_plan_halo_depth(const lbm_params* params, int parts, int math_mode);
 
 /* ---- create / destroy --------------------------------------------------------------------
  * Replaces the buffer set-up half of initialise() (SerialCode/d2q9-bgk.c:531-567) and

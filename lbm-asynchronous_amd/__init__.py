@@ -116,7 +116,7 @@ def load_library() -> ctypes.CDLL:
     lib.lbm_device_count.argtypes = []; lib.lbm_device_count.restype = I
     lib.lbm_partition_rows.argtypes = [I, I, I, PI, PI]; lib.lbm_partition_rows.restype = I
     lib.lbm_halo_plan.argtypes = [I, I, I, I, ctypes.POINTER(_CHaloOp)]; lib.lbm_halo_plan.restype = I
-    lib.lbm_plan_halo_depth.argtypes = [ctypes.POINTER(_CParams), I]; lib.lbm_plan_halo_depth.restype = I
+    lib.lbm_plan_halo_depth.argtypes = [ctypes.POINTER(_CParams), I, I]; lib.lbm_plan_halo_depth.restype = I
     lib.lbm_create.argtypes = [ctypes.POINTER(_CParams), P, P, I, I]; lib.lbm_create.restype = P
     lib.lbm_rccl_unique_id.argtypes = [P]; lib.lbm_rccl_unique_id.restype = I
     lib.lbm_create_rank.argtypes = [ctypes.POINTER(_CParams), P, P, I, I, P, I, I]
@@ -171,11 +171,11 @@ def halo_plan(rows: int, parts: int, index: int, depth: int) -> list[dict]:
             for o in ops]
 
 
-def plan_halo_depth(params: "Params", parts: int) -> int:
+def plan_halo_depth(params: "Params", parts: int, math: str | int = "exact") -> int:
     """Halo depth = timesteps per pass the engine uses for `parts` row slabs (lbm_plan_halo_depth)."""
     lib = load_library()
     cp = params._c()
-    d = lib.lbm_plan_halo_depth(ctypes.byref(cp), parts)
+    d = lib.lbm_plan_halo_depth(ctypes.byref(cp), parts, _MATH[math])
     if d <= 0:
         raise LbmError(lib.lbm_last_error().decode())
     return int(d)

@@ -232,6 +232,8 @@ struct lbm_ctx {
   int prefetch = 0;    // stream kernel: request the next row before relaxing the current one (LBM_PREFETCH)
   int xcd_chunk = 0;   // stream kernel: strips per XCD chunk (LBM_XCD_CHUNK; 0 = plain workgroup order)
   int use_stepk = 0;   // two-step passes through stepk_stream<K=2> instead of step2_stream (LBM_STEPK; experiments)
+  int packed = 0;      // stream kernel: collision on pairs of cells, v_pk_* instructions (LBM_PACKED)
+  int lds_windows = 0; // packed stream kernel: how many of the K-1 sliding windows live in LDS (LBM_LDS_WINDOWS, 0..2)
   int band_rows = 8, n_strips = 0;  // step2_stream geometry: band height, waves across x
   int lane_cells = 4;               // cells per lane in step2_stream (4 or 2; LBM_LANE_CELLS)
   SlabTeam* team = nullptr;         // one issuing thread per slab (one-process multi-GPU), or null
@@ -391,7 +393,19 @@ int launch_stepk(lbm_ctx* c, int s, hipStream_t stream, int k, int row_first, in
                          {lbm::stepk_stream<M, N, 4, 4, false>, lbm::stepk_stream<M, N, 4, 4, true>}}
   static const fn table[2][2][3][2] = {{LBM_K_ROW(0, false), LBM_K_ROW(0, true)}, {LBM_K_ROW(1, false), LBM_K_ROW(1, true)}};
 #undef LBM_K_ROW
-  const fn kernel = table[c->math_mode == LBM_MATH_EXACT ? 0 : 1][c->nts][k - 2][c->prefetch ? 1 : 0];
+  // exact arithmetic on pairs of cells (v_pk_* instructions): [nontemporal stores][k - 2][prefetch][windows in LDS]
+#define LBM_PK(N, KK, PF, Q) {lbm::stepk_pk<N, KK, PF, 0, Q>, lbm::stepk_pk<N, KK, PF, 1, Q>, lbm::stepk_pk<N, KK, PF, (KK > 2 ? 2 : 1), Q>}
+#define LBM_PK_ROW(N, Q) {{LBM_PK(N, 2, false, Q), LBM_PK(N, 2, true, Q)}, {LBM_PK(N, 3, false, Q), LBM_PK(N, 3, true, Q)}, \
+                          {LBM_PK(N, 4, false, Q), LBM_PK(N, 4, true, Q)}}
+  // [both pairs in one block][nontemporal stores][k - 2][prefetch][windows in LDS]
+  static const fn table_pk[2][2][3][2][3] = {{LBM_PK_ROW(false, false), LBM_PK_ROW(true, false)},
+                                             {LBM_PK_ROW(false, true), LBM_PK_ROW(true, true)}};
+#undef LBM_PK_ROW
+#undef LBM_PK
+  const int lds_windows = c->lds_windows < k ? c->lds_windows : k - 1;
+  const bool packed = c->packed && c->math_mode == LBM_MATH_EXACT;
+  const fn kernel = packed ? table_pk[c->packed == 2 ? 1 : 0][c->nts][k - 2][c->prefetch ? 1 : 0][lds_windows]
+                           : table[c->math_mode == LBM_MATH_EXACT ? 0 : 1][c->nts][k - 2][c->prefetch ? 1 : 0];
   if (done) hipExtLaunchKernelGGL(kernel, dim3(waves), dim3(64), 0, stream, nullptr, done, 0, a);
   else hipLaunchKernelGGL(kernel, dim3(waves), dim3(64), 0, stream, a);
   HIP_TRY(LBM_FAILURE, hipGetLastError());
@@ -401,7 +415,7 @@ int launch_stepk(lbm_ctx* c, int s, hipStream_t stream, int k, int row_first, in
 // the stream kernel for a k-step pass: the 2-cells-per-lane form exists for k = 2 only (step2_stream)
 int launch_pass(lbm_ctx* c, int s, hipStream_t stream, int k, int row_first, int row_end, int band_rows,
                 int band_pitch, int band_count, int part_offset, bool accel_after, hipEvent_t done = nullptr) {
-  if (c->lane_cells == 4 && (k > 2 || c->prefetch || c->xcd_chunk || c->use_stepk))
+  if (c->lane_cells == 4 && (k > 2 || c->prefetch || c->xcd_chunk || c->use_stepk || c->packed))
     return launch_stepk(c, s, stream, k, row_first, row_end, band_rows, band_pitch, band_count, part_offset, accel_after, done);
   return launch_step2(c, s, stream, row_first, row_end, band_rows, band_pitch, band_count, part_offset, accel_after, done);
 }
@@ -1131,7 +1145,7 @@ int build_slab(lbm_ctx* c, int s, const ObstacleSource& obst, const float* cells
 // many timesteps it takes per pass -- from global numbers only, so every rank of a multi-process run decides alike.
 // create_common and the host-only query lbm_plan_halo_depth share it.
 struct StreamPlan { bool vec4; int fuse2, lane_cells, pass_steps; };
-StreamPlan plan_stream(const lbm_params* params, int parts, bool halo_on) {
+StreamPlan plan_stream(const lbm_params* params, int parts, bool halo_on, int math_mode) {
   StreamPlan pl;
   // 4 cells per lane need nx % 4 == 0; tiny single-slab grids are latency-bound and run faster with one
   // cell per lane (4x the waves, a quarter of the dependent arithmetic per lane: 128^2 3.2 vs 5.0 us per
@@ -1146,11 +1160,13 @@ StreamPlan plan_stream(const lbm_params* params, int parts, bool halo_on) {
   // vs 70/113/125 one-step; 2048^2 over 8: 96 vs 261).
   pl.fuse2 = (pl.vec4 && env_int("LBM_FUSE2", (min_cells >= 560L * 1024 || halo_on) ? 1 : 0)) ? 1 : 0;
   pl.lane_cells = env_int("LBM_LANE_CELLS", min_cells >= 3L * 1024 * 1024 ? 4 : 2) == 2 ? 2 : 4;
-  // Timesteps per pass of the stream kernel.  The two-step kernel at 8192^2 is bound by DRAM traffic (round-2 PMC),
-  // so the 4-cell form runs THREE steps per pass (stepk_stream<K = 3>: 198-239 VGPRs, 2 waves per SIMD, the next
-  // row prefetched): 8192^2 0.345-0.353 vs 0.466-0.491 ms per step, 16384^2 1.39 vs 2.23, 4096^2 0.103 vs 0.134.
-  // K = 4 (245 VGPRs) is bound by VALU issue and slower (0.361).  The 2-cell form exists for K = 2 only.
-  pl.pass_steps = env_int("LBM_PASS_STEPS", pl.lane_cells == 4 ? 3 : 2);
+  // Timesteps per pass of the stream kernel.  The two-step kernel at 8192^2 is bound by DRAM traffic (round-2 PMC:
+  // 5.4-5.8 TB/s at the memory controllers whatever the band height or the arithmetic), so the 4-cell form runs more
+  // steps per pass: K = 3 (stepk_stream, 2 waves per SIMD, next row prefetched) 0.345 vs 0.47-0.49 ms per step, at
+  // which point it is bound by VALU issue again (K = 4 with scalar arithmetic: 0.36); with the collision on PAIRS of
+  // cells (stepk_pk: v_pk_* instructions, 108 instead of 155 lane-instructions per update) K = 4 pays: 0.275-0.285.
+  // The packed kernel exists for the exact arithmetic only; the 2-cell form for K = 2 only.
+  pl.pass_steps = env_int("LBM_PASS_STEPS", pl.lane_cells == 4 ? (math_mode == LBM_MATH_EXACT ? 4 : 3) : 2);
   if (pl.pass_steps < 2 || pl.pass_steps > kHaloRows || pl.lane_cells != 4) pl.pass_steps = 2;
   // across slabs a K-step pass needs slabs of at least 2K rows (the stream kernel at all: 4); a periodic slab at least K
   if (halo_on && min_rows < 2 * pl.pass_steps) pl.pass_steps = 2;
@@ -1216,7 +1232,7 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
   }
 
   const bool halo_on = (c->halo != HALO_SELF);
-  const StreamPlan plan = plan_stream(params, world * n_slabs, halo_on);
+  const StreamPlan plan = plan_stream(params, world * n_slabs, halo_on, math_mode);
   c->vec4 = plan.vec4;
 
   int max_blocks = 0;
@@ -1274,7 +1290,17 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
   c->lane_cells = plan.lane_cells;
   c->n_strips = ceil_div(params->nx / c->lane_cells > 0 ? params->nx / c->lane_cells : 1, lbm::kStripQuads);
   c->pass_steps = plan.pass_steps;
-  c->prefetch = env_int("LBM_PREFETCH", c->pass_steps == 3 ? 1 : 0) ? 1 : 0;  // K = 4 + prefetch spills
+  // Packed arithmetic (exact mode, 4 cells per lane): on.  With K = 4 two of the three sliding windows live in LDS
+  // (18 KB per wave), which leaves registers to prefetch the next row (216 VGPRs): us per step, this form | packed
+  // without prefetch / LDS | scalar K = 3: 16384^2 1091 | 1097 | 1355, 12288^2 640 | 652 | 838, 6144^2 180 | 187 | 233,
+  // 4096^2 75.3 | 78.1 | 94.7, 3072^2 45.6 | 45.3 | 59.0, 2048^2 24.9 | 26.3 | 31.9; a rank's share through the halo
+  // pipeline 8192x1024 45.1 | 46.7 | 55.3, 8192x2048 77.5 | 81.4 | 98.9, 8192x4096 149 | 152 | 187.
+  c->packed = env_int("LBM_PACKED", (math_mode == LBM_MATH_EXACT && c->lane_cells == 4) ? 1 : 0);  // 2: both pairs in one block
+  if (c->packed < 0 || c->packed > 2 || math_mode != LBM_MATH_EXACT) c->packed = 0;
+  c->lds_windows = env_int("LBM_LDS_WINDOWS", (c->packed && c->pass_steps == 4) ? 2 : 0);
+  if (c->lds_windows < 0 || c->lds_windows > 2 || !c->packed) c->lds_windows = 0;
+  // scalar K = 4 with prefetch spills (245 + 36 VGPRs); the packed K = 4 needs its LDS windows for it
+  c->prefetch = env_int("LBM_PREFETCH", (c->pass_steps == 3 || (c->pass_steps == 4 && c->lds_windows == 2)) ? 1 : 0) ? 1 : 0;
   // strips per XCD chunk: half a row of strips, for slabs of many rounds of waves only (12288^2 0.793 vs 0.832 ms per
   // step, 16384^2 1.369 vs 1.381).  Elsewhere the band height packs the waves tightly into rounds (below) and the
   // few empty workgroups of the chunked order spill into an extra round (4096^2: 0.135 vs 0.093).
@@ -1282,6 +1308,7 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
   c->xcd_chunk = env_int("LBM_XCD_CHUNK", (c->pass_steps >= 3 && many_rounds) ? ceil_div(c->n_strips, 2) : 0);
   if (c->xcd_chunk < 0 || c->xcd_chunk > c->n_strips) c->xcd_chunk = 0;
   c->use_stepk = env_int("LBM_STEPK", 0) ? 1 : 0;
+
   // Band height.  A wave sweeps band_rows + 2 rows.
   //   4-cell form (256 CUs x 12 waves resident): short bands, by row width -- measured optimum 7 rows at 8192 cells
   //   per row (8192^2: 0.477-0.480 ms vs 0.481-0.484 at 6, 0.495 at 4; same in the halo pipeline), 4-5 rows for
@@ -1470,9 +1497,10 @@ int lbm_halo_plan(int rows, int parts, int index, int depth, lbm_halo_op out[4])
   return LBM_SUCCESS;
 }
 
-int lbm_plan_halo_depth(const lbm_params* params, int parts) {
-  if (!validate_params(params) || parts < 1) LBM_FAIL(0, "lbm_plan_halo_depth: bad arguments");
-  const StreamPlan pl = plan_stream(params, parts, true);
+int lbm_plan_halo_depth(const lbm_params* params, int parts, int math_mode) {
+  if (!validate_params(params) || parts < 1 || (math_mode != LBM_MATH_EXACT && math_mode != LBM_MATH_FAST))
+    LBM_FAIL(0, "lbm_plan_halo_depth: bad arguments");
+  const StreamPlan pl = plan_stream(params, parts, true, math_mode);
   return pl.fuse2 ? pl.pass_steps : 1;
 }
 

@@ -29,6 +29,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace lbm {
 
 constexpr int kBlock = 256;  // 4 waves of 64
@@ -909,6 +911,382 @@ __global__ __launch_bounds__(64, (K >= 3 || PREFETCH) ? 2 : 3) void stepk_stream
         }
       }
     }
+  }
+
+#pragma unroll
+  for (int s = 0; s < K; s++) {
+    const float tot = wave_sum(sum[s]);
+    if (lane == 0) a.partials[(long)s * a.slot_stride + wave_id] = tot;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Packed arithmetic: two cells per instruction.
+//
+// With three or four timesteps per pass the stream kernel is bound by VALU issue again (a plain wave64 VALU
+// instruction holds a CDNA4 SIMD for 4 cycles whatever it computes).  gfx950 has packed fp32 VALU operations
+// (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32): one instruction, two independent IEEE fp32 results.  A lane's
+// four cells are therefore kept as two PAIRS (cells 0,1 and 2,3: the two halves of the 16-byte vectors the lane
+// loads and stores) and the whole collision is written on pairs.  Every packed operation below is the same
+// IEEE operation, in the same order, as in collide_exact / collide_exact_body / moments_shared -- results are
+// bit-identical; only the instruction count halves.  What cannot be packed stays per cell: v_rcp_f32, the range
+// guards, v_sqrt_f32.  Blocked cells and the (rare, wave-uniform) lid row are patched afterwards; a lane whose
+// guards fail (density outside [2^-60, 2^60) or |u|^2 >= 5e28: never in a physical run) recomputes its four
+// cells with the scalar code, so the exactness argument of div_const_fast holds unchanged.
+// ---------------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 splat2(float v) { return f2{v, v}; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 div_const_fast2(f2 x, float C, float R) {
+  const f2 q = x * splat2(R);
+  const f2 r = fma2(splat2(-C), q, x);
+  return fma2(r, splat2(R), q);
+}
+__device__ __forceinline__ f2 div_with_rcp2(f2 a, f2 b, f2 r) {
+  f2 q = a * r;
+  f2 e = fma2(-b, q, a);
+  q = fma2(e, r, q);
+  e = fma2(-b, q, a);
+  return fma2(e, r, q);
+}
+
+// One PAIR of cells of one row, no exceptions: stream inputs f[k] -> relaxed r[k] as if both cells were fluid
+// cells of an ordinary row; u_sq = their |u|^2 (pre-collision moments); returns false when a guard of the fast
+// constant divides / the shared reciprocal fails for either cell.
+__device__ __forceinline__ bool relax_pair_core(const f2 (&f)[kQ], float omega, f2 (&r)[kQ], f2& u_sq) {
+  constexpr float kInvCsq = 1.0f / kCsq, kInvTwoCsq = 1.0f / kTwoCsq, kInvTwoCsqSq = 1.0f / kTwoCsqSq;
+  f2 d = f[0];
+#pragma unroll
+  for (int k = 1; k < kQ; k++) d = d + f[k];
+  const f2 X = ((f[1] + f[5]) + f[8]) - ((f[3] + f[6]) + f[7]);
+  const f2 Y = ((f[2] + f[5]) + f[6]) - ((f[4] + f[7]) + f[8]);
+  bool ok = density_in_plain_range(d.x) && density_in_plain_range(d.y);
+  const f2 r0 = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  const f2 e0 = fma2(-d, r0, splat2(1.f));
+  const f2 rr = fma2(e0, r0, r0);
+  const f2 ux = div_with_rcp2(X, d, rr);
+  const f2 uy = div_with_rcp2(Y, d, rr);
+  const f2 uxx = ux * ux, uyy = uy * uy;
+  u_sq = uxx + uyy;
+  ok = ok && (u_sq.x < 5.0e28f) && (u_sq.y < 5.0e28f);
+  const f2 usq_term = div_const_fast2(u_sq, kTwoCsq, kInvTwoCsq);
+  const f2 one = splat2(1.f), om = splat2(omega);
+  {
+    const f2 w0r = splat2(kW0) * d;
+    r[0] = f[0] + om * (w0r * (one - usq_term) - f[0]);
+  }
+  {
+    const f2 w1r = splat2(kW1) * d;
+    const f2 x1 = div_const_fast2(ux, kCsq, kInvCsq), x2 = div_const_fast2(uxx, kTwoCsqSq, kInvTwoCsqSq);
+    r[1] = f[1] + om * (w1r * (((one + x1) + x2) - usq_term) - f[1]);
+    r[3] = f[3] + om * (w1r * (((one - x1) + x2) - usq_term) - f[3]);
+    const f2 y1 = div_const_fast2(uy, kCsq, kInvCsq), y2 = div_const_fast2(uyy, kTwoCsqSq, kInvTwoCsqSq);
+    r[2] = f[2] + om * (w1r * (((one + y1) + y2) - usq_term) - f[2]);
+    r[4] = f[4] + om * (w1r * (((one - y1) + y2) - usq_term) - f[4]);
+  }
+  {
+    const f2 w2r = splat2(kW2) * d;
+    const f2 us = ux + uy, ud = uy - ux;  // -ux + uy
+    const f2 s1 = div_const_fast2(us, kCsq, kInvCsq), s2 = div_const_fast2(us * us, kTwoCsqSq, kInvTwoCsqSq);
+    r[5] = f[5] + om * (w2r * (((one + s1) + s2) - usq_term) - f[5]);
+    r[7] = f[7] + om * (w2r * (((one - s1) + s2) - usq_term) - f[7]);
+    const f2 d1 = div_const_fast2(ud, kCsq, kInvCsq), d2 = div_const_fast2(ud * ud, kTwoCsqSq, kInvTwoCsqSq);
+    r[6] = f[6] + om * (w2r * (((one + d1) + d2) - usq_term) - f[6]);
+    r[8] = f[8] + om * (w2r * (((one - d1) + d2) - usq_term) - f[8]);
+  }
+  return ok;
+}
+
+// the exceptions of a pair, per cell: blocked cells bounce back, the lid row is accelerated, a failed guard sends the
+// cell through the scalar code (IEEE divides).  sp0 / sp1: the cells' |u| (0 for blocked cells).
+__device__ __forceinline__ void relax_pair_fixup(const f2 (&f)[kQ], bool ok, unsigned blocked, bool lid, float omega,
+                                                 float a1, float a2, f2 (&r)[kQ], bool want_speed, float& sp0, float& sp1) {
+  if (!ok || blocked != 0 || lid) {
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      const bool is_blocked = ((blocked >> (8 * c)) & 0xffu) != 0;
+      if (!ok || is_blocked || lid) {
+        float ts[kQ], rs[kQ], speed;
+#pragma unroll
+        for (int k = 0; k < kQ; k++) ts[k] = f[k][c];
+        relax_cell<0, 1>(ts, is_blocked, lid, omega, a1, a2, rs, speed, want_speed);
+#pragma unroll
+        for (int k = 0; k < kQ; k++) r[k][c] = rs[k];
+        if (c == 0) sp0 = speed; else sp1 = speed;
+      }
+    }
+  }
+}
+
+// One PAIR of cells of one row: stream inputs f[k] -> relaxed r[k]; returns the sum of |u| over its fluid cells
+// (SPEED = 1 form: pre-collision moments, native sqrt) when want_speed.
+// blocked: the pair's two mask bytes (bits 0-7, 8-15); lid: this row receives the next step's acceleration.
+__device__ __forceinline__ float relax_pair_exact(const f2 (&f)[kQ], unsigned blocked, bool lid, float omega,
+                                                  float a1, float a2, f2 (&r)[kQ], bool want_speed) {
+  f2 u_sq;
+  const bool ok = relax_pair_core(f, omega, r, u_sq);
+  float sp0 = 0.f, sp1 = 0.f;
+  if (want_speed) {
+    sp0 = __builtin_amdgcn_sqrtf(u_sq.x);
+    sp1 = __builtin_amdgcn_sqrtf(u_sq.y);
+  }
+  relax_pair_fixup(f, ok, blocked, lid, omega, a1, a2, r, want_speed, sp0, sp1);
+  return sp0 + sp1;
+}
+
+// Both pairs of a lane in one basic block: two independent dependency chains the scheduler can interleave (with two
+// waves per SIMD there is little else to fill the issue slots of a dependent chain); exceptions after both.
+__device__ __forceinline__ float relax_quad_exact(const f2 (&f0)[kQ], const f2 (&f1)[kQ], unsigned blocked, bool lid,
+                                                  float omega, float a1, float a2, f2 (&r0)[kQ], f2 (&r1)[kQ],
+                                                  bool want_speed) {
+  f2 usq0, usq1;
+  const bool ok0 = relax_pair_core(f0, omega, r0, usq0);
+  const bool ok1 = relax_pair_core(f1, omega, r1, usq1);
+  float sp[4] = {0.f, 0.f, 0.f, 0.f};
+  if (want_speed) {
+    sp[0] = __builtin_amdgcn_sqrtf(usq0.x);  sp[1] = __builtin_amdgcn_sqrtf(usq0.y);
+    sp[2] = __builtin_amdgcn_sqrtf(usq1.x);  sp[3] = __builtin_amdgcn_sqrtf(usq1.y);
+  }
+  relax_pair_fixup(f0, ok0, blocked & 0xffffu, lid, omega, a1, a2, r0, want_speed, sp[0], sp[1]);
+  relax_pair_fixup(f1, ok1, blocked >> 16, lid, omega, a1, a2, r1, want_speed, sp[2], sp[3]);
+  return (sp[0] + sp[1]) + (sp[2] + sp[3]);
+}
+
+// one pair (P = 0: cells 0,1; P = 1: cells 2,3) of a plane shifted by one cell: the value each cell receives from
+// its west (east) neighbour; W = the west lane's last cell, E = the east lane's first cell
+template <int P>
+__device__ __forceinline__ f2 pair_from_west(const f2 a0, const f2 a1, float W) {
+  if constexpr (P == 0) return f2{W, a0.x};
+  else return f2{a0.y, a1.x};
+}
+template <int P>
+__device__ __forceinline__ f2 pair_from_east(const f2 a0, const f2 a1, float E) {
+  if constexpr (P == 0) return f2{a0.y, a1.x};
+  else return f2{a1.y, E};
+}
+
+struct WindowPk {
+  f2 w256[3][2];  // speeds 2,5,6 of the row two below the newest, as pairs
+  f2 w013[3][2];  // speeds 0,1,3 of the row below the newest
+  f2 n256[3][2];  // speeds 2,5,6 of the row below the newest
+  unsigned m;
+};
+
+// stepk_stream with the collision on pairs (exact arithmetic, 4 cells per lane); same launch geometry and arguments.
+// LW of the K-1 sliding windows (the last ones) live in LDS instead of registers: a window is 36 floats per lane,
+// K = 4 needs three of them, and with all three in registers (252 VGPRs) nothing is left to prefetch the next row
+// into -- at two waves per SIMD the kernel then waits out every row's load latency (8192^2: 0.284 ms per step,
+// neither VALU- nor DRAM-bound).  An LDS window is nine 16-byte quads per lane (lane-linear: conflict-free
+// ds_read_b128 / ds_write_b128), private to the lane that wrote it, so no barrier is involved; speeds 2,5,6 sit in
+// a two-deep ring indexed by the row parity, speeds 0,1,3 in a single slot.  9 KB per window and wave.
+template <bool NTS, int K, bool PREFETCH, int LW, bool QUAD = false>
+__global__ __launch_bounds__(64, 2) void stepk_pk(const StepKArgs a) {
+  static_assert(K >= 2 && K <= 4 && LW >= 0 && LW <= K - 1, "one halo lane per side covers K <= 4 steps");
+  constexpr int C = 4;
+  typedef typename RowPull<C>::vec vec;
+  typedef float quad __attribute__((ext_vector_type(4)));
+  __shared__ quad lds_win[LW > 0 ? LW : 1][9][64];
+  const int lane = threadIdx.x;
+  int strip, band;
+  if (a.chunk > 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int chunks_per_band = (a.n_strips + a.chunk - 1) / a.chunk;
+    const int g = (j / a.chunk) * 8 + xcd;
+    band = g / chunks_per_band;
+    strip = (g - band * chunks_per_band) * a.chunk + j % a.chunk;
+    if (band >= a.n_bands || strip >= a.n_strips) return;
+  } else {
+    strip = blockIdx.x % a.n_strips;
+    band = blockIdx.x / a.n_strips;
+  }
+  const int wave_id = band * a.n_strips + strip;
+  const int units_x = a.nx / C;
+  const int y0 = a.row_first + band * a.band_pitch;
+  const int band_n = min(a.band_rows, a.row_end - y0);
+
+  const int ux_raw = strip * kStripQuads + lane - 1;
+  int ux = ux_raw % units_x;
+  if (ux < 0) ux += units_x;
+  const int x0 = ux * C;
+  const bool out_lane = (lane >= 1) && (lane <= kStripQuads) && (ux_raw < units_x);
+  const long ps = a.plane_stride;
+
+  Step2Args pa;
+  pa.src = a.src;  pa.mask = a.mask;  pa.plane_stride = a.plane_stride;  pa.row_pitch = a.row_pitch;
+  pa.pitch = a.pitch;  pa.rows = a.rows;  pa.wrap = a.wrap;
+
+  WindowPk win[K - 1];  // the first K-1-LW are used (registers); the others only for their mask bytes
+#pragma unroll
+  for (int s = 0; s < K - 1; s++) {
+    win[s].m = 0;
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+      for (int p = 0; p < 2; p++) win[s].w256[q][p] = win[s].w013[q][p] = win[s].n256[q][p] = splat2(0.f);
+  }
+  if constexpr (LW > 0) {
+#pragma unroll
+    for (int l = 0; l < LW; l++)
+#pragma unroll
+      for (int q = 0; q < 9; q++) lds_win[l][q][lane] = quad{0.f, 0.f, 0.f, 0.f};
+  }
+  float sum[K];
+#pragma unroll
+  for (int s = 0; s < K; s++) sum[s] = 0.f;
+
+  const int n_iter = band_n + 2 * (K - 1);
+  RowPull<C> nextp;
+  if constexpr (PREFETCH) nextp = pull_row<C>(pa, wrap_row(y0 - (K - 1), a.rows, a.wrap), x0);
+
+  for (int i = 0; i < n_iter; i++) {
+    // ---- stage 1: step t on row r, pulled from memory -------------------------------------------
+    const int r = wrap_row(y0 - (K - 1) + i, a.rows, a.wrap);
+    RowPull<C> p;
+    if constexpr (PREFETCH) {
+      p = nextp;
+      if (i + 1 < n_iter) nextp = pull_row<C>(pa, wrap_row(y0 - (K - 1) + i + 1, a.rows, a.wrap), x0);
+    } else {
+      p = pull_row<C>(pa, r, x0);
+    }
+    f2 cur[2][kQ];
+    {
+      const float e1 = lane_from_west<2>(p.v[1][3]), e5 = lane_from_west<2>(p.v[5][3]), e8 = lane_from_west<2>(p.v[8][3]);
+      const float e3 = lane_from_east<2>(p.v[3][0]), e6 = lane_from_east<2>(p.v[6][0]), e7 = lane_from_east<2>(p.v[7][0]);
+#define LBM_LO(v) f2{(v)[0], (v)[1]}
+#define LBM_HI(v) f2{(v)[2], (v)[3]}
+      const bool lid = (r == a.accel_row) || (r == a.accel_row2);
+      const bool own_row = (i >= K - 1) && (i < band_n + K - 1);
+      float sp = 0.f;
+      {
+        const f2 t0[kQ] = {LBM_LO(p.v[0]),
+                           pair_from_west<0>(LBM_LO(p.v[1]), LBM_HI(p.v[1]), e1),
+                           LBM_LO(p.v[2]),
+                           pair_from_east<0>(LBM_LO(p.v[3]), LBM_HI(p.v[3]), e3),
+                           LBM_LO(p.v[4]),
+                           pair_from_west<0>(LBM_LO(p.v[5]), LBM_HI(p.v[5]), e5),
+                           pair_from_east<0>(LBM_LO(p.v[6]), LBM_HI(p.v[6]), e6),
+                           pair_from_east<0>(LBM_LO(p.v[7]), LBM_HI(p.v[7]), e7),
+                           pair_from_west<0>(LBM_LO(p.v[8]), LBM_HI(p.v[8]), e8)};
+        if constexpr (!QUAD) sp += relax_pair_exact(t0, p.m & 0xffffu, lid, a.omega, a.a1, a.a2, cur[0], own_row);
+        const f2 t1[kQ] = {LBM_HI(p.v[0]),
+                           pair_from_west<1>(LBM_LO(p.v[1]), LBM_HI(p.v[1]), e1),
+                           LBM_HI(p.v[2]),
+                           pair_from_east<1>(LBM_LO(p.v[3]), LBM_HI(p.v[3]), e3),
+                           LBM_HI(p.v[4]),
+                           pair_from_west<1>(LBM_LO(p.v[5]), LBM_HI(p.v[5]), e5),
+                           pair_from_east<1>(LBM_LO(p.v[6]), LBM_HI(p.v[6]), e6),
+                           pair_from_east<1>(LBM_LO(p.v[7]), LBM_HI(p.v[7]), e7),
+                           pair_from_west<1>(LBM_LO(p.v[8]), LBM_HI(p.v[8]), e8)};
+        if constexpr (!QUAD) sp += relax_pair_exact(t1, p.m >> 16, lid, a.omega, a.a1, a.a2, cur[1], own_row);
+        else sp = relax_quad_exact(t0, t1, p.m, lid, a.omega, a.a1, a.a2, cur[0], cur[1], own_row);
+      }
+      if (own_row && out_lane) sum[0] += sp;
+    }
+    unsigned m_cur = p.m;
+
+    // ---- stages 2..K: step t+s on row r-s from window s and the stage-s results of row r-s+1 ------
+    bool alive = true;
+    auto stage = [&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      constexpr bool in_lds = (s - 1) >= (K - 1 - LW);
+      constexpr int li = in_lds ? (s - 1) - (K - 1 - LW) : 0;
+      if (!alive) return;
+      WindowPk& w = win[s - 1];
+      const int ring = (i & 1) * 3;
+      f2 nxt[2][kQ];
+      const bool active = (i >= 2 * s);
+      if (active) {
+        f2 w256[3][2], w013[3][2];
+        if constexpr (in_lds) {
+#pragma unroll
+          for (int q = 0; q < 3; q++) {
+            const quad A = lds_win[li][ring + q][lane], B = lds_win[li][6 + q][lane];
+            w256[q][0] = LBM_LO(A);  w256[q][1] = LBM_HI(A);
+            w013[q][0] = LBM_LO(B);  w013[q][1] = LBM_HI(B);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 3; q++)
+#pragma unroll
+            for (int p2 = 0; p2 < 2; p2++) { w256[q][p2] = w.w256[q][p2];  w013[q][p2] = w.w013[q][p2]; }
+        }
+        const int ro = wrap_row(y0 - (K - 1) + i - s, a.rows, a.wrap);
+        const float w1 = lane_from_west<2>(w013[1][1].y);
+        const float w5 = lane_from_west<2>(w256[1][1].y);
+        const float w8 = lane_from_west<2>(cur[1][8].y);
+        const float x3 = lane_from_east<2>(w013[2][0].x);
+        const float x6 = lane_from_east<2>(w256[2][0].x);
+        const float x7 = lane_from_east<2>(cur[0][7].x);
+        const bool last = (s == K - 1);
+        const bool lid = ((ro == a.accel_row) || (ro == a.accel_row2)) && (!last || a.accel_after);
+        const bool own_row = (i - s >= K - 1) && (i - s < band_n + K - 1);
+        float sp = 0.f;
+        {
+          const f2 u0[kQ] = {w013[0][0],
+                             pair_from_west<0>(w013[1][0], w013[1][1], w1),
+                             w256[0][0],
+                             pair_from_east<0>(w013[2][0], w013[2][1], x3),
+                             cur[0][4],
+                             pair_from_west<0>(w256[1][0], w256[1][1], w5),
+                             pair_from_east<0>(w256[2][0], w256[2][1], x6),
+                             pair_from_east<0>(cur[0][7], cur[1][7], x7),
+                             pair_from_west<0>(cur[0][8], cur[1][8], w8)};
+          if constexpr (!QUAD) sp += relax_pair_exact(u0, w.m & 0xffffu, lid, a.omega, a.a1, a.a2, nxt[0], own_row);
+          const f2 u1[kQ] = {w013[0][1],
+                             pair_from_west<1>(w013[1][0], w013[1][1], w1),
+                             w256[0][1],
+                             pair_from_east<1>(w013[2][0], w013[2][1], x3),
+                             cur[1][4],
+                             pair_from_west<1>(w256[1][0], w256[1][1], w5),
+                             pair_from_east<1>(w256[2][0], w256[2][1], x6),
+                             pair_from_east<1>(cur[0][7], cur[1][7], x7),
+                             pair_from_west<1>(cur[0][8], cur[1][8], w8)};
+          if constexpr (!QUAD) sp += relax_pair_exact(u1, w.m >> 16, lid, a.omega, a.a1, a.a2, nxt[1], own_row);
+          else sp = relax_quad_exact(u0, u1, w.m, lid, a.omega, a.a1, a.a2, nxt[0], nxt[1], own_row);
+        }
+        if (own_row && out_lane) sum[s] += sp;
+      }
+      // rotate window s with the stage-s row just consumed
+      const unsigned m_below = w.m;
+      if constexpr (in_lds) {
+        lds_win[li][ring + 0][lane] = quad{cur[0][2].x, cur[0][2].y, cur[1][2].x, cur[1][2].y};
+        lds_win[li][ring + 1][lane] = quad{cur[0][5].x, cur[0][5].y, cur[1][5].x, cur[1][5].y};
+        lds_win[li][ring + 2][lane] = quad{cur[0][6].x, cur[0][6].y, cur[1][6].x, cur[1][6].y};
+        lds_win[li][6][lane] = quad{cur[0][0].x, cur[0][0].y, cur[1][0].x, cur[1][0].y};
+        lds_win[li][7][lane] = quad{cur[0][1].x, cur[0][1].y, cur[1][1].x, cur[1][1].y};
+        lds_win[li][8][lane] = quad{cur[0][3].x, cur[0][3].y, cur[1][3].x, cur[1][3].y};
+      } else {
+#pragma unroll
+        for (int p2 = 0; p2 < 2; p2++) {
+          w.w256[0][p2] = w.n256[0][p2];  w.w256[1][p2] = w.n256[1][p2];  w.w256[2][p2] = w.n256[2][p2];
+          w.n256[0][p2] = cur[p2][2];     w.n256[1][p2] = cur[p2][5];     w.n256[2][p2] = cur[p2][6];
+          w.w013[0][p2] = cur[p2][0];     w.w013[1][p2] = cur[p2][1];     w.w013[2][p2] = cur[p2][3];
+        }
+      }
+      w.m = m_cur;
+      if (!active) { alive = false; return; }
+      m_cur = m_below;
+#pragma unroll
+      for (int p2 = 0; p2 < 2; p2++)
+#pragma unroll
+        for (int k = 0; k < kQ; k++) cur[p2][k] = nxt[p2][k];
+      if (s == K - 1 && out_lane) {
+        const int ro = wrap_row(y0 - (K - 1) + i - s, a.rows, a.wrap);
+        float* d_row = a.dst + (long)ro * a.row_pitch + x0;
+#pragma unroll
+        for (int k = 0; k < kQ; k++) {
+          const vec o = {cur[0][k].x, cur[0][k].y, cur[1][k].x, cur[1][k].y};
+          if constexpr (NTS) __builtin_nontemporal_store(o, reinterpret_cast<vec*>(d_row + k * ps));
+          else *reinterpret_cast<vec*>(d_row + k * ps) = o;
+        }
+      }
+    };
+    stage(std::integral_constant<int, 1>{});
+    if constexpr (K > 2) stage(std::integral_constant<int, 2>{});
+    if constexpr (K > 3) stage(std::integral_constant<int, 3>{});
+#undef LBM_LO
+#undef LBM_HI
   }
 
 #pragma unroll

@@ -130,8 +130,8 @@ def test_plan_halo_depth_follows_the_kernel_policy(lbm, monkeypatch):
     big = lbm.Params(8192, 8192, 10, 10, 0.1, 0.01, 1.85)
     ragged = lbm.Params(130, 64, 10, 10, 0.1, 0.005, 1.85)
     assert lbm.plan_halo_depth(small, 2) == 2          # two-step kernel, 2 cells per lane
-    assert lbm.plan_halo_depth(big, 8) == 3            # 8192x1024 per rank: three-step kernel
-    assert lbm.plan_halo_depth(big, 2) == 3
+    assert lbm.plan_halo_depth(big, 8) == 4            # 8192x1024 per rank: four-step packed kernel
+    assert lbm.plan_halo_depth(big, 2) == 4 and lbm.plan_halo_depth(big, 2, "fast") == 3
     assert lbm.plan_halo_depth(ragged, 2) == 1         # nx % 4 != 0: one step per pass
     monkeypatch.setenv("LBM_PASS_STEPS", "2")
     assert lbm.plan_halo_depth(big, 8) == 2

@@ -157,14 +157,14 @@ def test_8192_short_run_bitwise_vs_oracle(lbm, big_case, big_oracle_50, monkeypa
     SURVEY.md section 8d asks for) against the oracle's multi-threaded fused form; lattice and pressure
     bit-identical, av_vels by the check.py rule (big-grid parity through binary fields, not text files).
     slabs = 8: the same workload cut into the 8 row slabs config 4 gives its ranks (1024 rows each; here sharing
-    the device, halos by device copies -- RCCL cannot open 8 communicators on one device): three-step passes,
-    3-row halos, interior / boundary pipeline; 50 = 16 three-step passes + one two-step pass."""
+    the device, halos by device copies -- RCCL cannot open 8 communicators on one device): four-step passes,
+    4-row halos, interior / boundary pipeline; 50 = 12 four-step passes + one two-step pass."""
     p, ob = big_case
     steps, src, ref_av = big_oracle_50
     monkeypatch.setenv("LBM_HALO", "memcpy")
     with lbm.Engine(p, ob, None, n_gpus=slabs) as eng:
         info = eng.info()
-        assert info["n_slabs"] == slabs and info["steps_per_launch"] == 3
+        assert info["n_slabs"] == slabs and info["steps_per_launch"] == 4
         eng.run(steps)
         got_av = eng.av_vels(steps)
         got = eng.cells()                      # (ny, nx, 9)
@@ -200,7 +200,7 @@ def test_bench_rank_pipeline_checks_itself(lbm):
     assert rec["n_gpus"] == 1 and rec["steps"] == 31 and rec["results_finite"] is True
     assert rec["multi_gpu_check"]["fields_bitwise_equal_to_single_gpu_run"] is True
     assert rec["multi_gpu_check"]["av_vels_max_rel_diff"] < 5e-5
-    assert 0.0 < rec["roofline"]["frac"] <= 1.0 and rec["roofline"]["steps_per_launch"] == 3
+    assert 0.0 < rec["roofline"]["frac"] <= 1.0 and rec["roofline"]["steps_per_launch"] == 4
     assert len(rec["timing"]["repeats_ms_per_step"]) == 2
 
 
@@ -235,15 +235,15 @@ def test_cli_8192_tiled_run_against_oracle_cli(lbm, oracle, tmp_path):
 
 def test_8192_three_kernels_agree_bitwise_after_1001_steps(lbm, big_case, monkeypatch):
     """Size-independent cross-check at BASELINE's full size: the one-step kernel and the
-    several-steps-per-pass stream kernels (three steps = the default here, two steps with 4 and with 2
-    cells per lane) are independent implementations of the same arithmetic (different data flow,
+    several-steps-per-pass stream kernels (four steps on pairs of cells = the default here, three steps, two
+    steps with 4 and with 2 cells per lane) are independent implementations of the same arithmetic (different data flow,
     different neighbour exchange); after 1001 steps on 8192x8192 (1001 = 333 three-step passes + one
     two-step pass = 500 two-step passes + a one-step launch) their pressure and velocity fields must be
     bit-identical and mass conserved."""
     p0, ob = big_case
     p = lbm.Params(p0.nx, p0.ny, 1001, p0.reynolds_dim, p0.density, p0.accel, p0.omega)
     out = {}
-    for tag, fuse, lane_cells, pass_steps, spl in (("one", "0", "4", "3", 1), ("three", "1", "4", "3", 3),
+    for tag, fuse, lane_cells, pass_steps, spl in (("one", "0", "4", "3", 1), ("three", "1", "4", "3", 3), ("four", "1", "4", "4", 4),
                                                    ("two4", "1", "4", "2", 2), ("two2", "1", "2", "2", 2)):
         monkeypatch.setenv("LBM_FUSE2", fuse)
         monkeypatch.setenv("LBM_LANE_CELLS", lane_cells)
@@ -255,7 +255,7 @@ def test_8192_three_kernels_agree_bitwise_after_1001_steps(lbm, big_case, monkey
             assert eng.total_density() == pytest.approx(m0, rel=1e-6)
             f = eng.final_state()
             out[tag] = (f["pressure"].copy(), f["u"].copy(), eng.av_vels(1001))
-    for other in ("three", "two4", "two2"):
+    for other in ("four", "three", "two4", "two2"):
         assert np.array_equal(out["one"][0].view(np.uint32), out[other][0].view(np.uint32)), other
         assert np.array_equal(out["one"][1].view(np.uint32), out[other][1].view(np.uint32)), other
         # the stream kernels take |u| from the pre-collision moments (same lattice, ~1e-7 per cell): while the

@@ -10,7 +10,11 @@ from test_gpu_parity import AV_RTOL, random_case, run_both
 pytestmark = pytest.mark.gpu
 
 
-def force_stream(monkeypatch, k, band, prefetch=0, chunk=0, stepk=1):
+def force_stream(monkeypatch, k, band, prefetch=0, chunk=0, stepk=1, packed=None):
+    if packed is not None:
+        # packed: 0 = scalar stream kernel; 1 = collision on pairs; 11 / 12 = pairs, 1 / 2 sliding windows in LDS
+        monkeypatch.setenv("LBM_PACKED", "1" if packed else "0")
+        monkeypatch.setenv("LBM_LDS_WINDOWS", str(packed % 10 if packed > 1 else 0))
     monkeypatch.setenv("LBM_FUSE2", "1")
     monkeypatch.setenv("LBM_LANE_CELLS", "4")
     monkeypatch.setenv("LBM_PASS_STEPS", str(k))
@@ -20,20 +24,20 @@ def force_stream(monkeypatch, k, band, prefetch=0, chunk=0, stepk=1):
     monkeypatch.setenv("LBM_STEPK", str(stepk))
 
 
-@pytest.mark.parametrize("k", [2, 3])
+@pytest.mark.parametrize("k,packed", [(2, 0), (3, 0), (4, 0), (2, 1), (3, 1), (4, 1), (2, 11), (3, 12), (4, 11), (4, 12)])
 @pytest.mark.parametrize("band,prefetch,chunk", [(2, 0, 0), (7, 1, 0), (5, 0, 3), (64, 1, 1), (3, 1, 2)])
 @pytest.mark.parametrize("slabs,halo", [(1, None), (1, "rccl"), (2, "memcpy"), (3, "memcpy"), (8, "memcpy")])
-def test_k_steps_per_pass_bitwise(lbm, oracle, datasets, monkeypatch, k, band, prefetch, chunk, slabs, halo):
+def test_k_steps_per_pass_bitwise(lbm, oracle, datasets, monkeypatch, k, packed, band, prefetch, chunk, slabs, halo):
     """Reference data set 128x256 (periodic wrap in y live, wall row in the middle); 76 = 25 three-step passes
     + 1 single step, or 38 two-step passes; 77 ends a three-step run with a two-step pass."""
-    force_stream(monkeypatch, k, band, prefetch, chunk)
+    force_stream(monkeypatch, k, band, prefetch, chunk, packed=packed)
     if halo:
         monkeypatch.setenv("LBM_HALO", halo)
         if slabs == 1:
             monkeypatch.setenv("LBM_FORCE_HALO", "1")
     p, ob = datasets("128x256")
     cells = oracle.init_cells(p)
-    for steps in (76, 77):
+    for steps in (76, 77, 79):
         ref_cells, ref_av, got_cells, got_av, fields = run_both(lbm, oracle, p, ob, cells, steps, n_gpus=slabs)
         assert np.array_equal(ref_cells.view(np.uint32), got_cells.view(np.uint32)), steps
         np.testing.assert_allclose(got_av, ref_av, rtol=AV_RTOL)

@@ -177,12 +177,14 @@ def rank_main(rank, world, port, name, steps, out_dir, lag=0, seed=None, env=Non
         dist.destroy_process_group()
 
 
-THREE_STEP = {"LBM_FUSE2": "1", "LBM_LANE_CELLS": "4", "LBM_PASS_STEPS": "3"}   # what slabs of >= 3 Mi cells get
+FOUR_STEP = {"LBM_FUSE2": "1", "LBM_LANE_CELLS": "4"}                           # what slabs of >= 3 Mi cells get
+THREE_STEP = dict(FOUR_STEP, LBM_PASS_STEPS="3")                                # ... and in the fast-math mode
 
 
 @pytest.mark.parametrize("world,name,steps,env,depth", [(2, "128x128", 61, None, 2), (3, "128x256", 40, None, 2),
                                                         (2, "128x128", 62, THREE_STEP, 3), (3, "128x256", 43, THREE_STEP, 3),
-                                                        (4, "128x256", 31, THREE_STEP, 3)])
+                                                        (4, "128x256", 31, THREE_STEP, 3), (2, "128x128", 63, FOUR_STEP, 4),
+                                                        (3, "128x256", 45, FOUR_STEP, 4)])
 def test_row_sharded_ring_equals_single_domain(tmp_path, oracle, datasets, lbm, world, name, steps, env, depth):
     torch.set_num_threads(1)
     mp.spawn(rank_main, args=(world, free_port(), name, steps, str(tmp_path), 0, None, env), nprocs=world, join=True)

@@ -9,7 +9,7 @@ for b in ${BANDS:-7 32}; do
   for grp in "${GRPS[@]}"; do
     out=$GRAFT_REPO_ROOT/gpurun_out/pmcb_$b
     rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out -o p -- python3 $GRAFT_REPO_ROOT/bench.py --grid ${GRID:-8192x8192} --math ${MATH:-exact} --steps 12 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
-    for c in $grp; do python3 $GRAFT_REPO_ROOT/tools/pmc_mean.py $out/p_counter_collection.csv $c | grep -E "step2|step3|step_vec4" | sed "s/^/band $b ${MATH:-exact}: /"; done
+    for c in $grp; do python3 $GRAFT_REPO_ROOT/tools/pmc_mean.py $out/p_counter_collection.csv $c | grep -E "step2|stepk|step_vec4" | sed "s/^/band $b ${MATH:-exact}: /"; done
     rm -rf $out
   done
 done
