@@ -402,9 +402,16 @@ int launch_stepk(lbm_ctx* c, int s, hipStream_t stream, int k, int row_first, in
                                              {LBM_PK_ROW(false, true), LBM_PK_ROW(true, true)}};
 #undef LBM_PK_ROW
 #undef LBM_PK
+  // two cells per lane: one pair, two steps per pass: [nontemporal stores][prefetch][windows in LDS]
+  static const fn table_pk1[2][2][2] = {
+      {{lbm::stepk_pk<false, 2, false, 0, false, 1>, lbm::stepk_pk<false, 2, false, 1, false, 1>},
+       {lbm::stepk_pk<false, 2, true, 0, false, 1>, lbm::stepk_pk<false, 2, true, 1, false, 1>}},
+      {{lbm::stepk_pk<true, 2, false, 0, false, 1>, lbm::stepk_pk<true, 2, false, 1, false, 1>},
+       {lbm::stepk_pk<true, 2, true, 0, false, 1>, lbm::stepk_pk<true, 2, true, 1, false, 1>}}};
   const int lds_windows = c->lds_windows < k ? c->lds_windows : k - 1;
   const bool packed = c->packed && c->math_mode == LBM_MATH_EXACT;
-  const fn kernel = packed ? table_pk[c->packed == 2 ? 1 : 0][c->nts][k - 2][c->prefetch ? 1 : 0][lds_windows]
+  const fn kernel = (packed && c->lane_cells == 2) ? table_pk1[c->nts][c->prefetch ? 1 : 0][lds_windows ? 1 : 0]
+                    : packed ? table_pk[c->packed == 2 ? 1 : 0][c->nts][k - 2][c->prefetch ? 1 : 0][lds_windows]
                            : table[c->math_mode == LBM_MATH_EXACT ? 0 : 1][c->nts][k - 2][c->prefetch ? 1 : 0];
   if (done) hipExtLaunchKernelGGL(kernel, dim3(waves), dim3(64), 0, stream, nullptr, done, 0, a);
   else hipLaunchKernelGGL(kernel, dim3(waves), dim3(64), 0, stream, a);
@@ -415,7 +422,8 @@ int launch_stepk(lbm_ctx* c, int s, hipStream_t stream, int k, int row_first, in
 // the stream kernel for a k-step pass: the 2-cells-per-lane form exists for k = 2 only (step2_stream)
 int launch_pass(lbm_ctx* c, int s, hipStream_t stream, int k, int row_first, int row_end, int band_rows,
                 int band_pitch, int band_count, int part_offset, bool accel_after, hipEvent_t done = nullptr) {
-  if (c->lane_cells == 4 && (k > 2 || c->prefetch || c->xcd_chunk || c->use_stepk || c->packed))
+  if ((c->lane_cells == 4 && (k > 2 || c->prefetch || c->xcd_chunk || c->use_stepk || c->packed)) ||
+      (c->lane_cells == 2 && k == 2 && c->packed && c->math_mode == LBM_MATH_EXACT))
     return launch_stepk(c, s, stream, k, row_first, row_end, band_rows, band_pitch, band_count, part_offset, accel_after, done);
   return launch_step2(c, s, stream, row_first, row_end, band_rows, band_pitch, band_count, part_offset, accel_after, done);
 }
@@ -1159,7 +1167,7 @@ StreamPlan plan_stream(const lbm_params* params, int parts, bool halo_on, int ma
   // several timesteps per pass always pay there (1024^2 over 2/4/8 slabs on one device: 45/74/97 us per step
   // vs 70/113/125 one-step; 2048^2 over 8: 96 vs 261).
   pl.fuse2 = (pl.vec4 && env_int("LBM_FUSE2", (min_cells >= 560L * 1024 || halo_on) ? 1 : 0)) ? 1 : 0;
-  pl.lane_cells = env_int("LBM_LANE_CELLS", min_cells >= 3L * 1024 * 1024 ? 4 : 2) == 2 ? 2 : 4;
+  pl.lane_cells = env_int("LBM_LANE_CELLS", min_cells >= 3L * 512 * 1024 ? 4 : 2) == 2 ? 2 : 4;  // from 1.5 Mi cells
   // Timesteps per pass of the stream kernel.  The two-step kernel at 8192^2 is bound by DRAM traffic (round-2 PMC:
   // 5.4-5.8 TB/s at the memory controllers whatever the band height or the arithmetic), so the 4-cell form runs more
   // steps per pass: K = 3 (stepk_stream, 2 waves per SIMD, next row prefetched) 0.345 vs 0.47-0.49 ms per step, at
@@ -1279,11 +1287,12 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
   //   (one timestep per pass, step_vec4 / step_scalar: the odd last step of a run, widths that are not a multiple
   //                        of 4, LBM_FUSE2=0; it was the default up to 1.5 Mi cells until the two-step kernel stopped
   //                        computing |u| on its warm-up rows: 768^2 9.8 vs 11.3 us, 1024^2 12.35 vs 13.23, 1152^2 15.3 vs 18.1)
-  //   0.56 .. 3 Mi cells : two timesteps per pass, 2 cells per lane (93 VGPRs, 5 waves/SIMD: twice the
-  //                        waves of the 4-cell form; 1280^2: 19.1 vs 21.2 us, 1536^2: 22.2 vs 21.7-25.9 (three-step))
-  //   >= 3 Mi cells      : THREE timesteps per pass, 4 cells per lane (16-byte accesses; us per step, three-step |
-  //                        two-step 4-cell | two-step 2-cell: 1792^2 26.5 | - | 28.8, 2048^2 31.8 | 38.1 | 35.4,
-  //                        2560^2 41.8 | 62.4 | 59.4, 3072^2 59.0 | 76.0 | 90.5, 4096^2 93 | 129, 8192^2 340 | 492)
+  //   0.56 .. 1.5 Mi cells : two timesteps per pass, 2 cells per lane (one pair: 93-102 VGPRs, 4-5 waves/SIMD, twice
+  //                        the waves of the 4-cell form; packed arithmetic 768^2 7.9 vs 8.7 us, 1024^2 10.7 vs 11.0)
+  //   >= 1.5 Mi cells    : FOUR timesteps per pass on pairs of cells, 4 cells per lane (16-byte accesses; us per step,
+  //                        this form | 2-cell two-step: 1024^2 15.1 | 10.7, 1280^2 15.2 | 17.2, 1536^2 20.9 | 22.1,
+  //                        1792^2 22.1 | 28.2; three-step scalar | two-step: 2048^2 31.8 | 35.4, 3072^2 59.0 | 76.0,
+  //                        4096^2 93 | 129, 8192^2 340 | 492; four-step packed: 2048^2 24.9, 4096^2 75.3, 8192^2 277-285)
   // LBM_FUSE2, LBM_LANE_CELLS, LBM_BAND_ROWS override.  Ranks decide from global numbers only, so
   // every rank of a multi-process run takes the same path.
   c->fuse2 = plan.fuse2;
@@ -1295,7 +1304,8 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
   // without prefetch / LDS | scalar K = 3: 16384^2 1091 | 1097 | 1355, 12288^2 640 | 652 | 838, 6144^2 180 | 187 | 233,
   // 4096^2 75.3 | 78.1 | 94.7, 3072^2 45.6 | 45.3 | 59.0, 2048^2 24.9 | 26.3 | 31.9; a rank's share through the halo
   // pipeline 8192x1024 45.1 | 46.7 | 55.3, 8192x2048 77.5 | 81.4 | 98.9, 8192x4096 149 | 152 | 187.
-  c->packed = env_int("LBM_PACKED", (math_mode == LBM_MATH_EXACT && c->lane_cells == 4) ? 1 : 0);  // 2: both pairs in one block
+  c->packed = env_int("LBM_PACKED", math_mode == LBM_MATH_EXACT ? 1 : 0);  // 2: both pairs in one block (4 cells)
+  if (c->lane_cells == 2 && c->packed == 2) c->packed = 1;
   if (c->packed < 0 || c->packed > 2 || math_mode != LBM_MATH_EXACT) c->packed = 0;
   c->lds_windows = env_int("LBM_LDS_WINDOWS", (c->packed && c->pass_steps == 4) ? 2 : 0);
   if (c->lds_windows < 0 || c->lds_windows > 2 || !c->packed) c->lds_windows = 0;

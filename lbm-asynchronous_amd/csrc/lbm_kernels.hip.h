@@ -1053,23 +1053,24 @@ __device__ __forceinline__ float relax_quad_exact(const f2 (&f0)[kQ], const f2 (
   return (sp[0] + sp[1]) + (sp[2] + sp[3]);
 }
 
-// one pair (P = 0: cells 0,1; P = 1: cells 2,3) of a plane shifted by one cell: the value each cell receives from
-// its west (east) neighbour; W = the west lane's last cell, E = the east lane's first cell
-template <int P>
-__device__ __forceinline__ f2 pair_from_west(const f2 a0, const f2 a1, float W) {
-  if constexpr (P == 0) return f2{W, a0.x};
-  else return f2{a0.y, a1.x};
+// pair P of a plane (NP pairs per lane) shifted by one cell: the value each cell receives from its west (east)
+// neighbour; W = the west lane's last cell, E = the east lane's first cell
+template <int NP, int P>
+__device__ __forceinline__ f2 pair_from_west(const f2 (&a)[NP], float W) {
+  if constexpr (P == 0) return f2{W, a[0].x};
+  else return f2{a[P - 1].y, a[P].x};
 }
-template <int P>
-__device__ __forceinline__ f2 pair_from_east(const f2 a0, const f2 a1, float E) {
-  if constexpr (P == 0) return f2{a0.y, a1.x};
-  else return f2{a1.y, E};
+template <int NP, int P>
+__device__ __forceinline__ f2 pair_from_east(const f2 (&a)[NP], float E) {
+  if constexpr (P == NP - 1) return f2{a[P].y, E};
+  else return f2{a[P].y, a[P + 1].x};
 }
 
+template <int NP>
 struct WindowPk {
-  f2 w256[3][2];  // speeds 2,5,6 of the row two below the newest, as pairs
-  f2 w013[3][2];  // speeds 0,1,3 of the row below the newest
-  f2 n256[3][2];  // speeds 2,5,6 of the row below the newest
+  f2 w256[3][NP];  // speeds 2,5,6 of the row two below the newest, as pairs
+  f2 w013[3][NP];  // speeds 0,1,3 of the row below the newest
+  f2 n256[3][NP];  // speeds 2,5,6 of the row below the newest
   unsigned m;
 };
 
@@ -1080,13 +1081,14 @@ struct WindowPk {
 // neither VALU- nor DRAM-bound).  An LDS window is nine 16-byte quads per lane (lane-linear: conflict-free
 // ds_read_b128 / ds_write_b128), private to the lane that wrote it, so no barrier is involved; speeds 2,5,6 sit in
 // a two-deep ring indexed by the row parity, speeds 0,1,3 in a single slot.  9 KB per window and wave.
-template <bool NTS, int K, bool PREFETCH, int LW, bool QUAD = false>
-__global__ __launch_bounds__(64, 2) void stepk_pk(const StepKArgs a) {
-  static_assert(K >= 2 && K <= 4 && LW >= 0 && LW <= K - 1, "one halo lane per side covers K <= 4 steps");
-  constexpr int C = 4;
+// NP = pairs per lane: 2 (four cells, 16-byte accesses, K <= 4) or 1 (two cells, 8-byte accesses, K <= 2: a halo lane's
+// two cells cover two steps) -- the form for grids too small to fill the chip with four-cell lanes.
+template <bool NTS, int K, bool PREFETCH, int LW, bool QUAD = false, int NP = 2>
+__global__ __launch_bounds__(64, (NP == 1 && !PREFETCH) ? 4 : 2) void stepk_pk(const StepKArgs a) {
+  static_assert(K >= 2 && K <= 2 * NP && LW >= 0 && LW <= K - 1 && (NP == 2 || !QUAD), "one halo lane per side covers K <= C steps");
+  constexpr int C = 2 * NP;
   typedef typename RowPull<C>::vec vec;
-  typedef float quad __attribute__((ext_vector_type(4)));
-  __shared__ quad lds_win[LW > 0 ? LW : 1][9][64];
+  __shared__ vec lds_win[LW > 0 ? LW : 1][9][64];
   const int lane = threadIdx.x;
   int strip, band;
   if (a.chunk > 0) {
@@ -1116,24 +1118,77 @@ __global__ __launch_bounds__(64, 2) void stepk_pk(const StepKArgs a) {
   pa.src = a.src;  pa.mask = a.mask;  pa.plane_stride = a.plane_stride;  pa.row_pitch = a.row_pitch;
   pa.pitch = a.pitch;  pa.rows = a.rows;  pa.wrap = a.wrap;
 
-  WindowPk win[K - 1];  // the first K-1-LW are used (registers); the others only for their mask bytes
+  WindowPk<NP> win[K - 1];  // the first K-1-LW are used (registers); the others only for their mask bytes
 #pragma unroll
   for (int s = 0; s < K - 1; s++) {
     win[s].m = 0;
 #pragma unroll
     for (int q = 0; q < 3; q++)
 #pragma unroll
-      for (int p = 0; p < 2; p++) win[s].w256[q][p] = win[s].w013[q][p] = win[s].n256[q][p] = splat2(0.f);
+      for (int p = 0; p < NP; p++) win[s].w256[q][p] = win[s].w013[q][p] = win[s].n256[q][p] = splat2(0.f);
   }
   if constexpr (LW > 0) {
 #pragma unroll
     for (int l = 0; l < LW; l++)
 #pragma unroll
-      for (int q = 0; q < 9; q++) lds_win[l][q][lane] = quad{0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < 9; q++) {
+        vec z;
+#pragma unroll
+        for (int j = 0; j < C; j++) z[j] = 0.f;
+        lds_win[l][q][lane] = z;
+      }
   }
   float sum[K];
 #pragma unroll
   for (int s = 0; s < K; s++) sum[s] = 0.f;
+
+  // the NP pairs of one plane of a loaded / LDS vector, and back
+  auto pairs_of = [](const vec& v, f2 (&o)[NP]) {
+#pragma unroll
+    for (int p = 0; p < NP; p++) o[p] = f2{v[2 * p], v[2 * p + 1]};
+  };
+  auto vec_of = [](const f2 (&c)[NP][kQ], int k) {
+    vec o;
+#pragma unroll
+    for (int p = 0; p < NP; p++) { o[2 * p] = c[p][k].x;  o[2 * p + 1] = c[p][k].y; }
+    return o;
+  };
+  // relax the NP pairs of one row: inputs by plane (already shifted), pair-major outputs
+  auto relax_row = [&](const f2 (&in)[kQ][NP], unsigned m, bool lid, f2 (&out)[NP][kQ], bool own_row) {
+    f2 t0[kQ];
+#pragma unroll
+    for (int k = 0; k < kQ; k++) t0[k] = in[k][0];
+    if constexpr (NP == 1) {
+      return relax_pair_exact(t0, m & 0xffffu, lid, a.omega, a.a1, a.a2, out[0], own_row);
+    } else {
+      f2 t1[kQ];
+#pragma unroll
+      for (int k = 0; k < kQ; k++) t1[k] = in[k][NP - 1];
+      if constexpr (QUAD) {
+        return relax_quad_exact(t0, t1, m, lid, a.omega, a.a1, a.a2, out[0], out[NP - 1], own_row);
+      } else {
+        const float s0 = relax_pair_exact(t0, m & 0xffffu, lid, a.omega, a.a1, a.a2, out[0], own_row);
+        return s0 + relax_pair_exact(t1, m >> 16, lid, a.omega, a.a1, a.a2, out[NP - 1], own_row);
+      }
+    }
+  };
+  // the nine planes a cell pulls from: planes 0,2,4 as they are, 1,5,8 from the west, 3,6,7 from the east
+  auto shifted = [](const f2 (&pl)[kQ][NP], const float (&W)[kQ], const float (&E)[kQ], f2 (&in)[kQ][NP]) {
+#pragma unroll
+    for (int k = 0; k < kQ; k++) {
+      const bool west = (k == 1 || k == 5 || k == 8), east = (k == 3 || k == 6 || k == 7);
+      if (west) {
+        in[k][0] = pair_from_west<NP, 0>(pl[k], W[k]);
+        if constexpr (NP == 2) in[k][NP - 1] = pair_from_west<NP, NP - 1>(pl[k], W[k]);
+      } else if (east) {
+        in[k][0] = pair_from_east<NP, 0>(pl[k], E[k]);
+        if constexpr (NP == 2) in[k][NP - 1] = pair_from_east<NP, NP - 1>(pl[k], E[k]);
+      } else {
+#pragma unroll
+        for (int p = 0; p < NP; p++) in[k][p] = pl[k][p];
+      }
+    }
+  };
 
   const int n_iter = band_n + 2 * (K - 1);
   RowPull<C> nextp;
@@ -1149,38 +1204,18 @@ __global__ __launch_bounds__(64, 2) void stepk_pk(const StepKArgs a) {
     } else {
       p = pull_row<C>(pa, r, x0);
     }
-    f2 cur[2][kQ];
+    f2 cur[NP][kQ];
     {
-      const float e1 = lane_from_west<2>(p.v[1][3]), e5 = lane_from_west<2>(p.v[5][3]), e8 = lane_from_west<2>(p.v[8][3]);
-      const float e3 = lane_from_east<2>(p.v[3][0]), e6 = lane_from_east<2>(p.v[6][0]), e7 = lane_from_east<2>(p.v[7][0]);
-#define LBM_LO(v) f2{(v)[0], (v)[1]}
-#define LBM_HI(v) f2{(v)[2], (v)[3]}
+      float W[kQ] = {}, E[kQ] = {};
+      W[1] = lane_from_west<2>(p.v[1][C - 1]);  W[5] = lane_from_west<2>(p.v[5][C - 1]);  W[8] = lane_from_west<2>(p.v[8][C - 1]);
+      E[3] = lane_from_east<2>(p.v[3][0]);      E[6] = lane_from_east<2>(p.v[6][0]);      E[7] = lane_from_east<2>(p.v[7][0]);
+      f2 pl[kQ][NP], in[kQ][NP];
+#pragma unroll
+      for (int k = 0; k < kQ; k++) pairs_of(p.v[k], pl[k]);
+      shifted(pl, W, E, in);
       const bool lid = (r == a.accel_row) || (r == a.accel_row2);
       const bool own_row = (i >= K - 1) && (i < band_n + K - 1);
-      float sp = 0.f;
-      {
-        const f2 t0[kQ] = {LBM_LO(p.v[0]),
-                           pair_from_west<0>(LBM_LO(p.v[1]), LBM_HI(p.v[1]), e1),
-                           LBM_LO(p.v[2]),
-                           pair_from_east<0>(LBM_LO(p.v[3]), LBM_HI(p.v[3]), e3),
-                           LBM_LO(p.v[4]),
-                           pair_from_west<0>(LBM_LO(p.v[5]), LBM_HI(p.v[5]), e5),
-                           pair_from_east<0>(LBM_LO(p.v[6]), LBM_HI(p.v[6]), e6),
-                           pair_from_east<0>(LBM_LO(p.v[7]), LBM_HI(p.v[7]), e7),
-                           pair_from_west<0>(LBM_LO(p.v[8]), LBM_HI(p.v[8]), e8)};
-        if constexpr (!QUAD) sp += relax_pair_exact(t0, p.m & 0xffffu, lid, a.omega, a.a1, a.a2, cur[0], own_row);
-        const f2 t1[kQ] = {LBM_HI(p.v[0]),
-                           pair_from_west<1>(LBM_LO(p.v[1]), LBM_HI(p.v[1]), e1),
-                           LBM_HI(p.v[2]),
-                           pair_from_east<1>(LBM_LO(p.v[3]), LBM_HI(p.v[3]), e3),
-                           LBM_HI(p.v[4]),
-                           pair_from_west<1>(LBM_LO(p.v[5]), LBM_HI(p.v[5]), e5),
-                           pair_from_east<1>(LBM_LO(p.v[6]), LBM_HI(p.v[6]), e6),
-                           pair_from_east<1>(LBM_LO(p.v[7]), LBM_HI(p.v[7]), e7),
-                           pair_from_west<1>(LBM_LO(p.v[8]), LBM_HI(p.v[8]), e8)};
-        if constexpr (!QUAD) sp += relax_pair_exact(t1, p.m >> 16, lid, a.omega, a.a1, a.a2, cur[1], own_row);
-        else sp = relax_quad_exact(t0, t1, p.m, lid, a.omega, a.a1, a.a2, cur[0], cur[1], own_row);
-      }
+      const float sp = relax_row(in, p.m, lid, cur, own_row);
       if (own_row && out_lane) sum[0] += sp;
     }
     unsigned m_cur = p.m;
@@ -1192,73 +1227,52 @@ __global__ __launch_bounds__(64, 2) void stepk_pk(const StepKArgs a) {
       constexpr bool in_lds = (s - 1) >= (K - 1 - LW);
       constexpr int li = in_lds ? (s - 1) - (K - 1 - LW) : 0;
       if (!alive) return;
-      WindowPk& w = win[s - 1];
+      WindowPk<NP>& w = win[s - 1];
       const int ring = (i & 1) * 3;
-      f2 nxt[2][kQ];
+      f2 nxt[NP][kQ];
       const bool active = (i >= 2 * s);
       if (active) {
-        f2 w256[3][2], w013[3][2];
+        // planes of the window rows: 2,5,6 of row ro-1, 0,1,3 of row ro, and 4,7,8 of row ro+1 (= cur)
+        f2 pl[kQ][NP];
+        constexpr int q256[3] = {2, 5, 6}, q013[3] = {0, 1, 3};
         if constexpr (in_lds) {
 #pragma unroll
           for (int q = 0; q < 3; q++) {
-            const quad A = lds_win[li][ring + q][lane], B = lds_win[li][6 + q][lane];
-            w256[q][0] = LBM_LO(A);  w256[q][1] = LBM_HI(A);
-            w013[q][0] = LBM_LO(B);  w013[q][1] = LBM_HI(B);
+            pairs_of(lds_win[li][ring + q][lane], pl[q256[q]]);
+            pairs_of(lds_win[li][6 + q][lane], pl[q013[q]]);
           }
         } else {
 #pragma unroll
           for (int q = 0; q < 3; q++)
 #pragma unroll
-            for (int p2 = 0; p2 < 2; p2++) { w256[q][p2] = w.w256[q][p2];  w013[q][p2] = w.w013[q][p2]; }
+            for (int p2 = 0; p2 < NP; p2++) { pl[q256[q]][p2] = w.w256[q][p2];  pl[q013[q]][p2] = w.w013[q][p2]; }
         }
+#pragma unroll
+        for (int p2 = 0; p2 < NP; p2++) { pl[4][p2] = cur[p2][4];  pl[7][p2] = cur[p2][7];  pl[8][p2] = cur[p2][8]; }
+        float W[kQ] = {}, E[kQ] = {};
+        W[1] = lane_from_west<2>(pl[1][NP - 1].y);  W[5] = lane_from_west<2>(pl[5][NP - 1].y);  W[8] = lane_from_west<2>(pl[8][NP - 1].y);
+        E[3] = lane_from_east<2>(pl[3][0].x);       E[6] = lane_from_east<2>(pl[6][0].x);       E[7] = lane_from_east<2>(pl[7][0].x);
+        f2 in[kQ][NP];
+        shifted(pl, W, E, in);
         const int ro = wrap_row(y0 - (K - 1) + i - s, a.rows, a.wrap);
-        const float w1 = lane_from_west<2>(w013[1][1].y);
-        const float w5 = lane_from_west<2>(w256[1][1].y);
-        const float w8 = lane_from_west<2>(cur[1][8].y);
-        const float x3 = lane_from_east<2>(w013[2][0].x);
-        const float x6 = lane_from_east<2>(w256[2][0].x);
-        const float x7 = lane_from_east<2>(cur[0][7].x);
         const bool last = (s == K - 1);
         const bool lid = ((ro == a.accel_row) || (ro == a.accel_row2)) && (!last || a.accel_after);
         const bool own_row = (i - s >= K - 1) && (i - s < band_n + K - 1);
-        float sp = 0.f;
-        {
-          const f2 u0[kQ] = {w013[0][0],
-                             pair_from_west<0>(w013[1][0], w013[1][1], w1),
-                             w256[0][0],
-                             pair_from_east<0>(w013[2][0], w013[2][1], x3),
-                             cur[0][4],
-                             pair_from_west<0>(w256[1][0], w256[1][1], w5),
-                             pair_from_east<0>(w256[2][0], w256[2][1], x6),
-                             pair_from_east<0>(cur[0][7], cur[1][7], x7),
-                             pair_from_west<0>(cur[0][8], cur[1][8], w8)};
-          if constexpr (!QUAD) sp += relax_pair_exact(u0, w.m & 0xffffu, lid, a.omega, a.a1, a.a2, nxt[0], own_row);
-          const f2 u1[kQ] = {w013[0][1],
-                             pair_from_west<1>(w013[1][0], w013[1][1], w1),
-                             w256[0][1],
-                             pair_from_east<1>(w013[2][0], w013[2][1], x3),
-                             cur[1][4],
-                             pair_from_west<1>(w256[1][0], w256[1][1], w5),
-                             pair_from_east<1>(w256[2][0], w256[2][1], x6),
-                             pair_from_east<1>(cur[0][7], cur[1][7], x7),
-                             pair_from_west<1>(cur[0][8], cur[1][8], w8)};
-          if constexpr (!QUAD) sp += relax_pair_exact(u1, w.m >> 16, lid, a.omega, a.a1, a.a2, nxt[1], own_row);
-          else sp = relax_quad_exact(u0, u1, w.m, lid, a.omega, a.a1, a.a2, nxt[0], nxt[1], own_row);
-        }
+        const float sp = relax_row(in, w.m, lid, nxt, own_row);
         if (own_row && out_lane) sum[s] += sp;
       }
       // rotate window s with the stage-s row just consumed
       const unsigned m_below = w.m;
       if constexpr (in_lds) {
-        lds_win[li][ring + 0][lane] = quad{cur[0][2].x, cur[0][2].y, cur[1][2].x, cur[1][2].y};
-        lds_win[li][ring + 1][lane] = quad{cur[0][5].x, cur[0][5].y, cur[1][5].x, cur[1][5].y};
-        lds_win[li][ring + 2][lane] = quad{cur[0][6].x, cur[0][6].y, cur[1][6].x, cur[1][6].y};
-        lds_win[li][6][lane] = quad{cur[0][0].x, cur[0][0].y, cur[1][0].x, cur[1][0].y};
-        lds_win[li][7][lane] = quad{cur[0][1].x, cur[0][1].y, cur[1][1].x, cur[1][1].y};
-        lds_win[li][8][lane] = quad{cur[0][3].x, cur[0][3].y, cur[1][3].x, cur[1][3].y};
+        lds_win[li][ring + 0][lane] = vec_of(cur, 2);
+        lds_win[li][ring + 1][lane] = vec_of(cur, 5);
+        lds_win[li][ring + 2][lane] = vec_of(cur, 6);
+        lds_win[li][6][lane] = vec_of(cur, 0);
+        lds_win[li][7][lane] = vec_of(cur, 1);
+        lds_win[li][8][lane] = vec_of(cur, 3);
       } else {
 #pragma unroll
-        for (int p2 = 0; p2 < 2; p2++) {
+        for (int p2 = 0; p2 < NP; p2++) {
           w.w256[0][p2] = w.n256[0][p2];  w.w256[1][p2] = w.n256[1][p2];  w.w256[2][p2] = w.n256[2][p2];
           w.n256[0][p2] = cur[p2][2];     w.n256[1][p2] = cur[p2][5];     w.n256[2][p2] = cur[p2][6];
           w.w013[0][p2] = cur[p2][0];     w.w013[1][p2] = cur[p2][1];     w.w013[2][p2] = cur[p2][3];
@@ -1268,7 +1282,7 @@ __global__ __launch_bounds__(64, 2) void stepk_pk(const StepKArgs a) {
       if (!active) { alive = false; return; }
       m_cur = m_below;
 #pragma unroll
-      for (int p2 = 0; p2 < 2; p2++)
+      for (int p2 = 0; p2 < NP; p2++)
 #pragma unroll
         for (int k = 0; k < kQ; k++) cur[p2][k] = nxt[p2][k];
       if (s == K - 1 && out_lane) {
@@ -1276,7 +1290,7 @@ __global__ __launch_bounds__(64, 2) void stepk_pk(const StepKArgs a) {
         float* d_row = a.dst + (long)ro * a.row_pitch + x0;
 #pragma unroll
         for (int k = 0; k < kQ; k++) {
-          const vec o = {cur[0][k].x, cur[0][k].y, cur[1][k].x, cur[1][k].y};
+          const vec o = vec_of(cur, k);
           if constexpr (NTS) __builtin_nontemporal_store(o, reinterpret_cast<vec*>(d_row + k * ps));
           else *reinterpret_cast<vec*>(d_row + k * ps) = o;
         }
@@ -1285,8 +1299,6 @@ __global__ __launch_bounds__(64, 2) void stepk_pk(const StepKArgs a) {
     stage(std::integral_constant<int, 1>{});
     if constexpr (K > 2) stage(std::integral_constant<int, 2>{});
     if constexpr (K > 3) stage(std::integral_constant<int, 3>{});
-#undef LBM_LO
-#undef LBM_HI
   }
 
 #pragma unroll

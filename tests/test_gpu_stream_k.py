@@ -45,6 +45,28 @@ def test_k_steps_per_pass_bitwise(lbm, oracle, datasets, monkeypatch, k, packed,
         assert np.array_equal(ref_f["pressure"].view(np.uint32), fields["pressure"].view(np.uint32))
 
 
+@pytest.mark.parametrize("band,prefetch,lds", [(2, 0, 0), (3, 1, 0), (5, 0, 1), (8, 1, 1), (64, 0, 0)])
+@pytest.mark.parametrize("slabs,halo", [(1, None), (1, "rccl"), (3, "memcpy"), (8, "memcpy")])
+def test_two_cell_packed_kernel_bitwise(lbm, oracle, datasets, monkeypatch, band, prefetch, lds, slabs, halo):
+    """stepk_pk with ONE pair per lane (two cells, two steps per pass): the packed form of the mid-size kernel."""
+    force_stream(monkeypatch, 2, band, prefetch, 0, packed=1)
+    monkeypatch.setenv("LBM_LANE_CELLS", "2")
+    monkeypatch.setenv("LBM_LDS_WINDOWS", str(lds))
+    if halo:
+        monkeypatch.setenv("LBM_HALO", halo)
+        if slabs == 1:
+            monkeypatch.setenv("LBM_FORCE_HALO", "1")
+    p, ob = datasets("128x256")
+    cells = oracle.init_cells(p)
+    for steps in (76, 77):
+        ref_cells, ref_av, got_cells, got_av, _ = run_both(lbm, oracle, p, ob, cells, steps, n_gpus=slabs)
+        assert np.array_equal(ref_cells.view(np.uint32), got_cells.view(np.uint32)), steps
+        np.testing.assert_allclose(got_av, ref_av, rtol=AV_RTOL)
+    p, ob, cells = random_case(lbm, 250 * 2, 37, 77, walls=False)       # ragged strips, both wraps live
+    ref_cells, ref_av, got_cells, got_av, _ = run_both(lbm, oracle, p, ob, cells, 21, n_gpus=slabs)
+    assert np.array_equal(ref_cells.view(np.uint32), got_cells.view(np.uint32))
+
+
 def test_three_step_info_and_pieces(lbm, oracle, datasets, monkeypatch):
     """lbm_run in pieces of every residue mod 3 with three slabs: each piece starts with its own accelerate
     pass and exchange and may end with a two-step or a one-step pass."""
