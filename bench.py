@@ -288,8 +288,12 @@ def main():
                 roof["traffic_over_compulsory"] = t / compulsory_bytes
                 roof["traffic_GBps_at_this_runs_launch_time"] = t / (launch_ms * 1e-3) / 1e9
             if pmc.get("valu_busy") is not None:
-                roof["limiter"] = {"valu_busy": pmc["valu_busy"], "what": pmc.get("limiter_note"),
-                                   "source": "same committed profile"}
+                issue = pmc.get("issue_busy")
+                roof["limiter"] = {"bound": "instruction issue" if (issue or 0) > 0.75 or pmc["valu_busy"] > 0.75 else "hbm",
+                                   "frac": issue if issue is not None else pmc["valu_busy"],
+                                   "valu_busy": pmc["valu_busy"], "issue_busy": issue,
+                                   "lane_instructions_per_update": pmc.get("lane_instructions_per_update"),
+                                   "what": pmc.get("limiter_note"), "source": "same committed profile"}
         line = {
             "metric": "MLUPS", "value": mlups, "unit": "MLUPS (million lattice updates/s)",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,

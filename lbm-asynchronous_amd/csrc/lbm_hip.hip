@@ -1311,11 +1311,12 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
   if (c->lds_windows < 0 || c->lds_windows > 2 || !c->packed) c->lds_windows = 0;
   // scalar K = 4 with prefetch spills (245 + 36 VGPRs); the packed K = 4 needs its LDS windows for it
   c->prefetch = env_int("LBM_PREFETCH", (c->pass_steps == 3 || (c->pass_steps == 4 && c->lds_windows == 2)) ? 1 : 0) ? 1 : 0;
-  // strips per XCD chunk: half a row of strips, for slabs of many rounds of waves only (12288^2 0.793 vs 0.832 ms per
-  // step, 16384^2 1.369 vs 1.381).  Elsewhere the band height packs the waves tightly into rounds (below) and the
-  // few empty workgroups of the chunked order spill into an extra round (4096^2: 0.135 vs 0.093).
+  // strips per XCD chunk: a whole band of strips, for slabs of many rounds of waves only (16384^2, K = 4: 1.033 ms per
+  // step with 67-strip chunks, 1.088 with 34, 1.107 without; K = 3: 12288^2 0.793 vs 0.832).  Elsewhere the band height
+  // packs the waves tightly into rounds (below) and the few empty workgroups of the chunked order spill into an
+  // extra round (4096^2: 0.135 vs 0.093; 8192^2: 0.298 vs 0.288).
   const bool many_rounds = (long)c->n_strips * ceil_div(c->row_count / n_slabs, 24) >= 16L * 1024;
-  c->xcd_chunk = env_int("LBM_XCD_CHUNK", (c->pass_steps >= 3 && many_rounds) ? ceil_div(c->n_strips, 2) : 0);
+  c->xcd_chunk = env_int("LBM_XCD_CHUNK", (c->pass_steps >= 3 && many_rounds) ? c->n_strips : 0);
   if (c->xcd_chunk < 0 || c->xcd_chunk > c->n_strips) c->xcd_chunk = 0;
   c->use_stepk = env_int("LBM_STEPK", 0) ? 1 : 0;
 
@@ -1345,22 +1346,26 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
       }
     }
     if (c->lane_cells == 4 && c->pass_steps >= 3) {
-      // K >= 3 (2 waves per SIMD, VALU-bound): the busiest SIMD runs ceil(waves / 1024) waves of band + 2(K-1) row
-      // iterations each, so the cost of a band height is their product (8192^2: 44 rows = 6358 waves -> 7 x 48 =
-      // 0.389 ms per step, 46 rows = 6086 waves -> 6 x 50 = 0.350).  Slabs of many rounds are DRAM-bound and
-      // flat in the height (16384^2: 16 / 24 / 32 / 46 rows = 1.397 / 1.394 / 1.415 / 1.432): 24 rows there.
+      // K >= 3 (2 waves per SIMD, bound by instruction issue): the waves run in rounds of 2048 and every wave of a round
+      // takes band + 2(K-1) row iterations, so the cost of a band height is rounds x iterations (8192^2, K = 4: 46 rows
+      // = 6086 waves = 2.97 rounds 0.274 ms per step; 55 rows = 2.47 rounds 0.288; 58 rows 0.300; 64 rows 0.309;
+      // 24 / 32 rows 0.293 / 0.296; K = 3: 44 rows = 3.10 rounds 0.389, 46 rows 0.350).
       const long interior = (n_slabs > 1 || world > 1 || halo_on) ? rows_eff + 4 - 2 * c->pass_steps : rows_eff;
       const long r_int = interior > 1 ? interior : 1;
       const int warm = 2 * (c->pass_steps - 1);
       if ((long)c->n_strips * ceil_div(r_int, 24) >= 16L * 1024) {
-        pick = 24;
+        pick = 32;  // many rounds (XCD-chunked order): flat in the height, 16384^2 24 / 32 / model (48) = 1.078 / 1.077 / 1.098
       } else {
-        long best = -1;
+        // rounds of 2048 resident waves; a last round that fills at most half of the slots leaves one wave per SIMD,
+        // which then runs at nearly twice the speed
+        double best = -1.0;
         for (int b = 8; b <= 64; b++) {
           const long waves = (long)c->n_strips * ceil_div(r_int, b);
-          const long per_simd = (waves + 1023) / 1024;
-          const long cost = (per_simd < 2 ? 2 : per_simd) * (b + warm);  // a lone wave on a SIMD hides no latency
-          if (best < 0 || cost < best) { best = cost; pick = b; }
+          const long full = waves / 2048, rest = waves % 2048;
+          double rounds = (double)full + (rest == 0 ? 0.0 : (rest > 1024 ? 1.0 : 0.6));
+          if (rounds < 1.0) rounds = 1.0;  // a lone wave on a SIMD hides no latency
+          const double cost = rounds * (b + warm);
+          if (best < 0.0 || cost < best) { best = cost; pick = b; }
         }
       }
     }
