@@ -44,9 +44,14 @@ extern "C" {
 /* How a pass across several slabs / ranks treats its halo rows */
 #define LBM_HALO_SYNC  0 /* halo rows of the same timestep: the MPI_Waitall pattern
                             (MPI_Waitall/d2q9-bgk.c:225-253); results equal the single-domain run */
-#define LBM_HALO_STALE 1 /* halo rows one pass old: reproducible analogue of the reference's
+#define LBM_HALO_STALE 1 /* EXPERIMENTAL.  Halo rows one pass old: reproducible analogue of the reference's
                             MPI_Testall "stale halo" variant (MPI_Testall_OptimizedVersion/
-                            d2q9-bgk.c:256-301); no pass ever waits for an exchange of its own */
+                            d2q9-bgk.c:256-301); no pass ever waits for an exchange of its own.
+                            Parity unpinned (the reference variant is non-deterministic, so no fixture
+                            can exist); measured against the synchronous run by the check.py rule it
+                            misses 1 % in dense decompositions: av_vels 4.7 % (128x256 / 2 slabs, step 2),
+                            4.0 % (128x128 / 8 slabs, mid-transient), 1.2 % (256x256 / 4 slabs);
+                            pressure stays within 0.01 % */
 
 /* Run constants: field-for-field the reference's t_param (SerialCode/d2q9-bgk.c:66-75). */
 typedef struct {

@@ -92,14 +92,20 @@ def test_switching_modes_between_runs(lbm, oracle, monkeypatch):
         assert np.array_equal(eng.cells().view(np.uint32), c.view(np.uint32))
 
 
-@pytest.mark.parametrize("slabs,tol_pct", [(2, CHECK_TOL_PCT), (8, 5.0)])
+@pytest.mark.parametrize("slabs,tol_pct", [
+    (2, CHECK_TOL_PCT),
+    pytest.param(8, CHECK_TOL_PCT, marks=pytest.mark.xfail(strict=True, reason=(
+        "EXPERIMENTAL mode, parity unpinned: with 8 slabs of 16 rows the one-step halo lag moves av_vels by up to "
+        "4.0 % mid-transient (0.5 % at the end) -- outside check.py's 1 % rule, which takes the maximum over steps"))),
+    (8, 5.0)])
 def test_stale_halo_full_run_against_synchronous(lbm, datasets, monkeypatch, slabs, tol_pct):
     """The reference's accuracy claim for stale halos, on its 128x128 data set at full length: av_vels
     and pressure against the synchronous run by the check.py rule (check/check.py:83-99,136-148).
     A one-step delay per slab boundary leaves steady states alone but stretches the transient: with
     2 slabs the run stays inside the 1 % rule; with 8 slabs of 16 rows (one boundary every 16 rows,
     far denser than any sensible decomposition) av_vels deviate by up to 4 % mid-transient and 0.5 %
-    at the end -- recorded here as a bound, not hidden.  Mass is conserved up to what is in flight."""
+    at the end: the 1 % rule is kept as an expected failure there, and the measured deviation is
+    bounded at 5 %.  Mass is conserved up to what is in flight."""
     monkeypatch.setenv("LBM_HALO", "memcpy")
     p, ob = datasets("128x128")
     out = {}
