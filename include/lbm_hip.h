@@ -17,8 +17,8 @@
  * every compute entry point fails.
  *
  * Data layout on the device: structure-of-arrays interleaved by row, fp32 --
- * value (speed k, row y, column x) at base + (y*9 + k)*pitch + x -- with two halo rows below
- * and above the rows a slab owns; uint8 obstacle mask.
+ * value (speed k, row y, column x) at base + (y*9 + k)*pitch + x -- with four halo rows below
+ * and above the rows a slab owns (a K-step pass reads K rows beyond the slab, K <= 4); uint8 obstacle mask.
  * Host-facing arrays keep the reference's layouts: cells are array-of-structures
  * (9 consecutive floats per cell, cell index ii + jj*nx, SerialCode/d2q9-bgk.c:78-81),
  * obstacles are int[ny*nx] with 1 = blocked (:541, :570-601).

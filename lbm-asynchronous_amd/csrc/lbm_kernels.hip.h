@@ -7,11 +7,12 @@
 //   halo rows stored around the slab), bounce back on blocked cells, BGK-relax fluid cells, sum
 //   |u| of the relaxed cells into one partial per workgroup, and apply the NEXT step's
 //   accelerate_flow to the lid row before storing (so no separate pass over that row is needed).
-// step_vec4 / step_scalar advance one timestep per pass over memory, step2_stream two.
+// step_vec4 / step_scalar advance one timestep per pass over memory, step2_stream two, stepk_stream / stepk_pk
+// two to four (stepk_pk with the collision on pairs of cells: packed fp32 instructions), step_tile several from LDS.
 //
 // Layout: structure of arrays interleaved by row -- value (k, y, x) lives at
 // base + y*row_pitch + k*plane_stride + x with plane_stride = pitch and row_pitch = 9*pitch, i.e.
-// the 9 planes of one row lie next to each other (36*nx bytes), rows follow each other, and two
+// the 9 planes of one row lie next to each other (36*nx bytes), rows follow each other, and four
 // halo rows sit below row 0 and above row rows-1.  Every access is a contiguous, 16-byte-aligned
 // run along x of ONE speed (fully coalesced), and a workgroup's 9+9 streams fall into a ~1 MB
 // window instead of 18 windows 256 MiB apart: measured 10-13 % faster than 9 whole-grid planes on
