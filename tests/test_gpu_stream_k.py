@@ -157,3 +157,47 @@ def test_rank_rows_form_equals_global_form(lbm, oracle, monkeypatch):
     with lbm.Engine(tile_p, ob, None, rank=0, world_size=1, unique_id=lbm.rccl_unique_id(), device=0,
                     tiled=True) as eng:
         assert eng.info()["fluid_cells"] == 2 * int((ob == 0).sum())
+
+
+@pytest.mark.parametrize("kernel", ["tile", "one-step", "two-cell packed", "four-step packed", "three-step scalar"])
+def test_guard_paths_stay_bit_exact(lbm, oracle, monkeypatch, kernel):
+    """The fast constant divides and the shared reciprocal are guarded (density within [2^-60, 2^60), |u|^2 < 5e28);
+    cells outside take the IEEE divides -- in the packed kernels per lane, after the packed computation.  A lattice
+    with patches of populations scaled by 1e-22 and 1e+20 (densities 1e-23 and 1e+19) and a few cells with momenta
+    far above their density drives every kernel family through those paths; results must still equal the oracle's
+    bits (all values stay finite)."""
+    env = {"tile": {}, "one-step": {"LBM_FUSE2": "0"},
+           "two-cell packed": {"LBM_FUSE2": "1", "LBM_LANE_CELLS": "2"},
+           "four-step packed": {"LBM_FUSE2": "1", "LBM_LANE_CELLS": "4"},
+           "three-step scalar": {"LBM_FUSE2": "1", "LBM_LANE_CELLS": "4", "LBM_PACKED": "0", "LBM_PASS_STEPS": "3"}}[kernel]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    p, ob, cells = random_case(lbm, 256, 40, 4242, walls=False)
+    rng = np.random.default_rng(7)
+    cells[5:9, 10:40] *= np.float32(1e-22)
+    cells[20:23, 100:180] *= np.float32(1e20)
+    for _ in range(12):                                   # isolated cells with |u| >> 1
+        y, x = int(rng.integers(0, 40)), int(rng.integers(0, 256))
+        cells[y, x, 1] *= np.float32(1e6)
+    steps = 9
+    ref_cells, ref_av, got_cells, got_av, _ = run_both(lbm, oracle, p, ob, cells, steps)
+    assert np.isfinite(ref_cells).all()
+    assert np.array_equal(ref_cells.view(np.uint32), got_cells.view(np.uint32))
+    assert np.isfinite(got_av).all()
+
+
+def test_fast_math_three_step_kernel_within_check_tolerance(lbm, oracle, datasets, monkeypatch):
+    """FAST arithmetic on large grids runs the scalar stream kernel with three steps per pass; forced here at test
+    size (4 cells per lane) and held to the check.py rule against the oracle, like the other fast-mode kernels."""
+    monkeypatch.setenv("LBM_FUSE2", "1")
+    monkeypatch.setenv("LBM_LANE_CELLS", "4")
+    p, ob = datasets("128x128")
+    cells = oracle.init_cells(p)
+    steps = 2000
+    ref_cells, ref_av, got_cells, got_av, fields = run_both(lbm, oracle, p, ob, cells, steps, math="fast")
+    with lbm.Engine(p, ob, None, math="fast") as eng:
+        assert eng.info()["steps_per_launch"] == 3
+    ref_f = oracle.final_state(p, ref_cells, ob)
+    assert lbm.check_passes(ref_av, got_av, 1.0)
+    assert lbm.check_passes(ref_f["pressure"], fields["pressure"], 1.0)
+    np.testing.assert_allclose(got_av, ref_av, rtol=2e-4)
