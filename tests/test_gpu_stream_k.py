@@ -201,3 +201,16 @@ def test_fast_math_three_step_kernel_within_check_tolerance(lbm, oracle, dataset
     assert lbm.check_passes(ref_av, got_av, 1.0)
     assert lbm.check_passes(ref_f["pressure"], fields["pressure"], 1.0)
     np.testing.assert_allclose(got_av, ref_av, rtol=2e-4)
+
+
+@pytest.mark.parametrize("nx,ny,slabs", [(4100, 400, 1), (8192, 200, 1), (16384, 100, 2), (2052, 1000, 3), (6148, 300, 1),
+                                         (1600, 1000, 1), (8192, 8, 1), (2048, 2048, 4)])
+def test_default_policy_on_odd_shapes(lbm, oracle, monkeypatch, nx, ny, slabs):
+    """Nothing forced: whatever kernel and geometry the policy picks for wide-and-short, ragged-pitch (nx % 64 != 0)
+    and multi-slab shapes of >= 1.5 Mi cells must reproduce the oracle (random lattice, both wraps live)."""
+    monkeypatch.setenv("LBM_HALO", "memcpy")
+    p, ob, cells = random_case(lbm, nx, ny, nx + ny, blocked_frac=0.02, walls=False)
+    steps = 11
+    ref_cells, ref_av, got_cells, got_av, _ = run_both(lbm, oracle, p, ob, cells, steps, n_gpus=slabs)
+    assert np.array_equal(ref_cells.view(np.uint32), got_cells.view(np.uint32))
+    np.testing.assert_allclose(got_av, ref_av, rtol=AV_RTOL)
