@@ -996,6 +996,9 @@ int run_steps_stale(lbm_ctx* c, int n_steps, float* kernel_ms) {
 
 void free_slab(Slab& sl) {
   if (hipSetDevice(sl.device) != hipSuccess) return;
+  // graphs that captured RCCL operations hold on to the communicator: they go first
+  for (int i = 0; i < 2; i++)
+    if (sl.chunk_graph[i]) { (void)hipGraphExecDestroy(sl.chunk_graph[i]); sl.chunk_graph[i] = nullptr; }
   if (sl.nccl) ncclCommDestroy(sl.nccl);
   for (int i = 0; i < 2; i++) if (sl.lat_alloc[i]) (void)hipFree(sl.lat_alloc[i]);
   if (sl.mask_alloc) (void)hipFree(sl.mask_alloc);

@@ -214,3 +214,24 @@ def test_default_policy_on_odd_shapes(lbm, oracle, monkeypatch, nx, ny, slabs):
     ref_cells, ref_av, got_cells, got_av, _ = run_both(lbm, oracle, p, ob, cells, steps, n_gpus=slabs)
     assert np.array_equal(ref_cells.view(np.uint32), got_cells.view(np.uint32))
     np.testing.assert_allclose(got_av, ref_av, rtol=AV_RTOL)
+
+
+def test_graph_replay_of_rank_pipeline_opt_in(lbm):
+    """LBM_GRAPH=1 with halos (opt-in): 20-32 passes of the I / X / B pipeline -- both streams, RCCL send/recv inside
+    the capture -- replayed as one hipGraphLaunch per chunk must give the same fields as launch-by-launch issue.
+    Runs in a fresh process (system RCCL; with torch's bundled RCCL 2.26.6 loaded the instantiate step crashes, which is
+    one reason the mode is off by default).  A crash or hang of the runtime is reported as an expected failure of this
+    experimental mode, a wrong result as a real one."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    import os
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "graph_rank.py"), "1024x512", "300"],
+                             capture_output=True, text=True, timeout=150, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        pytest.xfail("hipGraph replay of the RCCL pipeline hung on this box (opt-in mode)")
+    if out.returncode != 0:
+        pytest.xfail(f"hipGraph replay of the RCCL pipeline crashed on this box (opt-in mode): rc {out.returncode}")
+    assert "'graph_steps': 64" in out.stdout
+    assert "fields equal: True" in out.stdout, out.stdout[-800:]
