@@ -26,6 +26,8 @@
 #ifndef LBM_HIP_H
 #define LBM_HIP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -182,6 +184,28 @@ lbm_ctx* lbm_create_tiled(const lbm_params* params, const int* tile, int tile_nx
 lbm_ctx* lbm_create_rank_tiled(const lbm_params* params, const int* tile, int tile_nx, int tile_ny,
                                int rank, int world_size, const void* unique_id, int device,
                                int math_mode);
+
+/*
+ * One process per GPU with the HOST's own message passing instead of RCCL -- the closest fit to the reference's MPI
+ * programs, which keep MPI_Isend / MPI_Irecv / MPI_Waitall (MPI_Waitall/d2q9-bgk.c:225-243) and MPI_Reduce
+ * (:321): the engine hands the boundary rows of a pass to `exchange` in pinned host buffers and takes the halo rows
+ * back, and sums its per-rank totals through `allreduce_sum`.
+ *   exchange(user, 4, ops, buffers, floats): the four messages of lbm_halo_plan in posting order; for ops[i].is_send
+ *     send buffers[i][0 .. floats) to rank ops[i].peer, else receive that many floats from it into buffers[i].  Post all
+ *     four before waiting for any (two ranks are each other's north AND south neighbour).  Return 0 on success.
+ *   allreduce_sum(user, values, n): in-place sum of n doubles over all ranks; every rank receives it.  Return 0.
+ * The callbacks block the host, so this transport does not hide the exchange behind the interior rows; it exists for
+ * MPI-launched hosts and to run the rank decomposition with several ranks on ONE device (tests).  obstacles /
+ * cells_aos: the global arrays, as lbm_create_rank.  Every rank must issue the same sequence of calls.
+ */
+typedef struct {
+  int (*exchange)(void* user, int n_ops, const lbm_halo_op* ops, float* const* buffers, size_t floats_per_message);
+  int (*allreduce_sum)(void* user, double* values, int n);
+  void* user;
+} lbm_host_comm;
+lbm_ctx* lbm_create_rank_hosted(const lbm_params* params, const int* obstacles, const float* cells_aos,
+                                int rank, int world_size, const lbm_host_comm* comm, int device,
+                                int math_mode);
 
 void     lbm_destroy(lbm_ctx* ctx);
 int      lbm_get_info(const lbm_ctx* ctx, lbm_info* out);

@@ -40,7 +40,7 @@ _HALO = {"sync": HALO_SYNC, "stale": HALO_STALE, HALO_SYNC: HALO_SYNC, HALO_STAL
 ABI_SYMBOLS = (
     "lbm_set_error_mode", "lbm_last_error", "lbm_version", "lbm_device_count",
     "lbm_partition_rows", "lbm_halo_plan", "lbm_plan_halo_depth", "lbm_create", "lbm_rccl_unique_id", "lbm_create_rank", "lbm_create_rank_rows",
-    "lbm_create_tiled", "lbm_create_rank_tiled", "lbm_destroy",
+    "lbm_create_tiled", "lbm_create_rank_tiled", "lbm_create_rank_hosted", "lbm_destroy",
     "lbm_get_info", "lbm_set_halo_mode", "lbm_run", "lbm_sync", "lbm_run_timed", "lbm_read_av_vels", "lbm_read_cells",
     "lbm_read_final_state", "lbm_av_velocity", "lbm_total_density", "lbm_calc_reynolds",
 )
@@ -68,6 +68,15 @@ class _CInfo(ctypes.Structure):
 class _CHaloOp(ctypes.Structure):
     _fields_ = [("is_send", ctypes.c_int), ("peer", ctypes.c_int), ("row_first", ctypes.c_int),
                 ("row_count", ctypes.c_int)]
+
+
+_EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(_CHaloOp),
+                                ctypes.POINTER(ctypes.POINTER(ctypes.c_float)), ctypes.c_size_t)
+_ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int)
+
+
+class _CHostComm(ctypes.Structure):
+    _fields_ = [("exchange", _EXCHANGE_FN), ("allreduce_sum", _ALLREDUCE_FN), ("user", ctypes.c_void_p)]
 
 
 @dataclass
@@ -126,6 +135,8 @@ def load_library() -> ctypes.CDLL:
     lib.lbm_create_tiled.argtypes = [ctypes.POINTER(_CParams), P, I, I, P, I, I]; lib.lbm_create_tiled.restype = P
     lib.lbm_create_rank_tiled.argtypes = [ctypes.POINTER(_CParams), P, I, I, I, I, P, I, I]
     lib.lbm_create_rank_tiled.restype = P
+    lib.lbm_create_rank_hosted.argtypes = [ctypes.POINTER(_CParams), P, P, I, I, ctypes.POINTER(_CHostComm), I, I]
+    lib.lbm_create_rank_hosted.restype = P
     lib.lbm_destroy.argtypes = [P]; lib.lbm_destroy.restype = None
     lib.lbm_get_info.argtypes = [P, ctypes.POINTER(_CInfo)]; lib.lbm_get_info.restype = I
     lib.lbm_set_halo_mode.argtypes = [P, I]; lib.lbm_set_halo_mode.restype = I
@@ -198,7 +209,7 @@ class Engine:
     def __init__(self, params: Params, obstacles: np.ndarray, cells: np.ndarray | None = None,
                  n_gpus: int = 1, math: str | int = "exact", *, rank: int | None = None,
                  world_size: int | None = None, unique_id: bytes | None = None, device: int = 0,
-                 tiled: bool = False, local_rows: bool = False):
+                 tiled: bool = False, local_rows: bool = False, host_comm=None):
         """obstacles: the global (ny, nx) map; with tiled=True a small (tile_ny, tile_nx) map repeated
         periodically over the grid (lbm_create_tiled / lbm_create_rank_tiled: the mask is expanded on the
         device); with local_rows=True (rank form only) this rank's rows preceded and followed by
@@ -232,7 +243,13 @@ class Engine:
             cptr = cells.ctypes.data
         cp = params._c()
         idbuf = ctypes.create_string_buffer(unique_id, RCCL_ID_BYTES) if unique_id else None
-        if rank is None:
+        if host_comm is not None:
+            if rank is None or tiled or local_rows:
+                raise LbmError("host_comm needs the rank form with the global obstacle map")
+            self._host_comm = self._wrap_host_comm(*host_comm)
+            h = self.lib.lbm_create_rank_hosted(ctypes.byref(cp), obstacles.ctypes.data, cptr, rank, world_size,
+                                                ctypes.byref(self._host_comm), device, _MATH[math])
+        elif rank is None:
             if tiled:
                 h = self.lib.lbm_create_tiled(ctypes.byref(cp), obstacles.ctypes.data, obstacles.shape[1],
                                               obstacles.shape[0], cptr, n_gpus, _MATH[math])
@@ -252,6 +269,33 @@ class Engine:
         if not h:
             raise LbmError(self.lib.lbm_last_error().decode())
         self.handle = ctypes.c_void_p(h)
+
+    @staticmethod
+    def _wrap_host_comm(exchange, allreduce_sum):
+        def c_exchange(_user, n_ops, ops, buffers, floats):
+            try:
+                plan = [{"is_send": bool(ops[i].is_send), "peer": ops[i].peer, "row_first": ops[i].row_first,
+                         "row_count": ops[i].row_count} for i in range(n_ops)]
+                views = [np.ctypeslib.as_array(buffers[i], shape=(floats,)) for i in range(n_ops)]
+                exchange(plan, views)
+                return 0
+            except Exception:                   # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def c_allreduce(_user, values, n):
+            try:
+                allreduce_sum(np.ctypeslib.as_array(values, shape=(n,)))
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        comm = _CHostComm(_EXCHANGE_FN(c_exchange), _ALLREDUCE_FN(c_allreduce), None)
+        comm._keep = (c_exchange, c_allreduce)   # the callbacks must outlive the context
+        return comm
 
     # -- lifecycle ---------------------------------------------------------------------------
     def close(self) -> None:

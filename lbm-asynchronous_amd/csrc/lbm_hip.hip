@@ -27,7 +27,7 @@ namespace {
 constexpr int kMaxSlabs = 8;
 constexpr int kPartSlots = lbm::kPartSlotsMax;  // steps whose partial sums are buffered before one reduce launch
 
-enum HaloMode { HALO_SELF = 0, HALO_MEMCPY = 1, HALO_RCCL = 2 };
+enum HaloMode { HALO_SELF = 0, HALO_MEMCPY = 1, HALO_RCCL = 2, HALO_HOST = 3 };
 
 // ---- error handling (reference: die(), SerialCode/d2q9-bgk.c:745-751) -----------------------
 int g_error_mode = LBM_ERRORS_DIE;
@@ -219,7 +219,11 @@ struct lbm_ctx {
   int halo = HALO_SELF;
   int halo_mode = LBM_HALO_SYNC;  // LBM_HALO_STALE: passes consume the halos of the previous pass
   int rank = 0, world = 1;  // multi-process
-  bool ranked = false;      // created by lbm_create_rank (owns an ncclCommInitRank communicator)
+  bool ranked = false;      // created by lbm_create_rank* (one process per GPU: rank / world describe the ring)
+  bool hosted = false;      // ... with the host's own message passing instead of RCCL (lbm_create_rank_hosted)
+  lbm_host_comm host_comm = {nullptr, nullptr, nullptr};
+  float* host_send[2] = {nullptr, nullptr};  // pinned staging buffers of the hosted exchange: kHaloRows rows each
+  float* host_recv[2] = {nullptr, nullptr};
   int row_first = 0, row_count = 0;
   int slot_fill = 0;  // partial slots used since the last reduce
   long part_stride = 0;
@@ -534,6 +538,28 @@ int exchange_halos(lbm_ctx* c, int depth, int src, int dst, int slot) {
         HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_x[slot], sl.comm));
       }
     }
+    return LBM_SUCCESS;
+  }
+  if (c->halo == HALO_HOST) {
+    // the host's own message passing (MPI in the reference: MPI_Isend / MPI_Irecv / MPI_Waitall, MPI_Waitall/
+    // d2q9-bgk.c:225-243): boundary rows to pinned host buffers, the host's exchange callback, halo rows back.
+    // The callback blocks the host, so this transport does not overlap the interior rows -- it exists so that the
+    // decomposition can run under an MPI-style launcher and be tested with several ranks on one device.
+    if (stale) LBM_FAIL(LBM_FAILURE, "the stale-halo mode is not available with the hosted exchange");
+    Slab& sl = c->slab[0];
+    lbm_halo_op ops[4];
+    if (lbm_halo_plan(sl.rows, c->world, c->rank, depth, ops) != LBM_SUCCESS) return LBM_FAILURE;
+    float* bufs[4] = {c->host_send[0], c->host_send[1], c->host_recv[0], c->host_recv[1]};
+    HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+    for (int i = 0; i < 2; i++)
+      HIP_TRY(LBM_FAILURE, hipMemcpyAsync(bufs[i], sl.lat[src] + (long)ops[i].row_first * c->row_pitch, (size_t)n * sizeof(float),
+                                          hipMemcpyDeviceToHost, sl.comm));
+    HIP_TRY(LBM_FAILURE, hipStreamSynchronize(sl.comm));
+    if (c->host_comm.exchange(c->host_comm.user, 4, ops, bufs, (size_t)n) != 0)
+      LBM_FAIL(LBM_FAILURE, "the host's halo exchange callback failed");
+    for (int i = 2; i < 4; i++)
+      HIP_TRY(LBM_FAILURE, hipMemcpyAsync(sl.lat[dst] + (long)ops[i].row_first * c->row_pitch, bufs[i], (size_t)n * sizeof(float),
+                                          hipMemcpyHostToDevice, sl.comm));
     return LBM_SUCCESS;
   }
   if (c->halo == HALO_MEMCPY) {
@@ -1188,7 +1214,7 @@ StreamPlan plan_stream(const lbm_params* params, int parts, bool halo_on, int ma
 
 lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, const float* cells_aos,
                        int n_slabs, int math_mode, int rank, int world, const void* unique_id,
-                       int device) {
+                       int device, const lbm_host_comm* host_comm = nullptr) {
   if (!validate_params(params)) LBM_FAIL(nullptr, "lbm_create: invalid parameters");
   if (!obst.data) LBM_FAIL(nullptr, "lbm_create: obstacles is NULL");
   if (obst.kind == OBST_TILE && (obst.tile_nx < 1 || obst.tile_ny < 1))
@@ -1227,8 +1253,10 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
     return nullptr;
   }
   const bool force_halo = env_int("LBM_FORCE_HALO", 0) != 0;
-  c->ranked = (unique_id != nullptr);
-  if (world > 1 || (c->ranked && force_halo)) c->halo = HALO_RCCL;
+  c->ranked = (unique_id != nullptr) || (host_comm != nullptr);
+  c->hosted = (host_comm != nullptr);
+  if (c->hosted) c->host_comm = *host_comm;
+  if (world > 1 || (c->ranked && force_halo)) c->halo = c->hosted ? HALO_HOST : HALO_RCCL;
   else if (n_slabs > 1 || force_halo) {
     const char* h = getenv("LBM_HALO");
     bool distinct = (n_slabs <= ndev);
@@ -1413,7 +1441,16 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
       return nullptr;
     }
 
-  if (c->ranked) {
+  if (c->hosted) {
+    for (int i = 0; i < 2; i++) {
+      const size_t bytes = (size_t)kHaloRows * c->row_pitch * sizeof(float);
+      if (hipHostMalloc(&c->host_send[i], bytes) != hipSuccess || hipHostMalloc(&c->host_recv[i], bytes) != hipSuccess) {
+        raise_error(__LINE__, "lbm_create_rank_hosted: cannot allocate the pinned exchange buffers");
+        lbm_destroy(c);
+        return nullptr;
+      }
+    }
+  } else if (c->ranked) {
     // one process per GPU: the communicator spans the ranks (also used for the av_vels reduce)
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof(id));
@@ -1439,7 +1476,15 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
   {
     long long fluid = 0;
     for (int s = 0; s < n_slabs; s++) fluid += c->slab[s].fluid_cells;
-    if (c->ranked && world > 1) {
+    if (c->hosted && world > 1) {
+      double v = (double)fluid;  // exact: a cell count is below 2^31
+      if (c->host_comm.allreduce_sum(c->host_comm.user, &v, 1) != 0) {
+        raise_error(__LINE__, "lbm_create_rank_hosted: the host's all-reduce callback failed");
+        lbm_destroy(c);
+        return nullptr;
+      }
+      fluid = (long long)(v + 0.5);
+    } else if (c->ranked && world > 1) {
       Slab& sl = c->slab[0];
       long long* dev = reinterpret_cast<long long*>(sl.scratch);
       if (hipSetDevice(sl.device) != hipSuccess ||
@@ -1472,7 +1517,7 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
   // (host issue 11.1 vs 11.6 us per step for a rank with RCCL self-exchange at 256^2: the runtime still enqueues every
   // node) and hipGraphInstantiate overflows its stack on the larger pipelines (3+ slabs with device-copy halos, a
   // rank's 20-pass chunk at 8192x1024) -- profiles/r02_tuning.md.  The device-copy transport never uses it.
-  if (c->halo != HALO_SELF && (!getenv("LBM_GRAPH") || c->halo == HALO_MEMCPY)) c->use_graph = 0;
+  if (c->halo != HALO_SELF && (!getenv("LBM_GRAPH") || c->halo != HALO_RCCL)) c->use_graph = 0;
   if (want_team) {
     c->use_graph = 0;
     c->team = new SlabTeam();
@@ -1577,6 +1622,14 @@ lbm_ctx* lbm_create_rank_rows(const lbm_params* params, const int* obstacle_rows
   return create_common(params, obst, cells_rows_aos, 1, math_mode, rank, world_size, unique_id, device);
 }
 
+lbm_ctx* lbm_create_rank_hosted(const lbm_params* params, const int* obstacles, const float* cells_aos,
+                                int rank, int world_size, const lbm_host_comm* comm, int device, int math_mode) {
+  if (world_size < 1 || rank < 0 || rank >= world_size) LBM_FAIL(nullptr, "lbm_create_rank_hosted: bad rank %d of %d", rank, world_size);
+  if (!comm || !comm->exchange || !comm->allreduce_sum) LBM_FAIL(nullptr, "lbm_create_rank_hosted: the exchange and all-reduce callbacks are required");
+  const ObstacleSource obst = {OBST_GLOBAL, obstacles, 0, 0, false};
+  return create_common(params, obst, cells_aos, 1, math_mode, rank, world_size, nullptr, device, comm);
+}
+
 lbm_ctx* lbm_create_rank_tiled(const lbm_params* params, const int* tile, int tile_nx, int tile_ny,
                                int rank, int world_size, const void* unique_id, int device, int math_mode) {
   if (!rank_args_ok(rank, world_size, unique_id)) return nullptr;
@@ -1599,6 +1652,10 @@ void lbm_destroy(lbm_ctx* c) {
     }
   }
   for (int s = 0; s < c->n_slabs; s++) free_slab(c->slab[s]);
+  for (int i = 0; i < 2; i++) {
+    if (c->host_send[i]) (void)hipHostFree(c->host_send[i]);
+    if (c->host_recv[i]) (void)hipHostFree(c->host_recv[i]);
+  }
   delete c;
 }
 
@@ -1662,7 +1719,11 @@ int lbm_read_av_vels(lbm_ctx* c, float* out, int n) {
     HIP_TRY(LBM_FAILURE, hipMemcpy(part.data(), c->slab[s].tot_u, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     for (int t = 0; t < n; t++) total[(size_t)t] += part[(size_t)t];
   }
-  if (c->ranked) {
+  if (c->hosted) {
+    // the reference's MPI_Reduce(av_vels, SUM) (MPI/d2q9-bgk.c:298-309) through the host's own all-reduce
+    if (c->world > 1 && c->host_comm.allreduce_sum(c->host_comm.user, total.data(), n) != 0)
+      LBM_FAIL(LBM_FAILURE, "the host's all-reduce callback failed");
+  } else if (c->ranked) {
     // the reference's MPI_Reduce(av_vels, SUM) (MPI/d2q9-bgk.c:298-309), as an all-reduce
     Slab& sl = c->slab[0];
     double* tmp = sl.reduce_buf;  // allocated once at create: nothing to leak on an error return
@@ -1751,7 +1812,10 @@ static int lattice_totals(lbm_ctx* c, double* speed, double* mass) {
     HIP_TRY(LBM_FAILURE, hipStreamSynchronize(sl.compute));
     for (int i = 0; i < kSumBlocks; i++) { tot[0] += h[i]; tot[1] += h[kSumBlocks + i]; }
   }
-  if (c->ranked) {
+  if (c->hosted) {
+    if (c->world > 1 && c->host_comm.allreduce_sum(c->host_comm.user, tot, 2) != 0)
+      LBM_FAIL(LBM_FAILURE, "the host's all-reduce callback failed");
+  } else if (c->ranked) {
     Slab& sl = c->slab[0];
     HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
     HIP_TRY(LBM_FAILURE, hipMemcpy(sl.scratch, tot, 2 * sizeof(double), hipMemcpyHostToDevice));
