@@ -337,8 +337,6 @@ int launch_step2(lbm_ctx* c, int s, hipStream_t stream, int row_first, int row_e
   a.a2 = c->p.density * c->p.accel / 36.f;
   a.partials1 = sl.partials + (long)c->slot_fill * c->part_stride + part_offset;
   a.partials2 = a.partials1 + c->part_stride;
-  static const int stagger = env_int("LBM_STAGGER", 0);
-  a.stagger = stagger;
   const int waves = c->n_strips * band_count;
   typedef void (*fn)(const lbm::Step2Args);
   // [math][nontemporal stores][cells per lane: 0 -> 4, 1 -> 2]

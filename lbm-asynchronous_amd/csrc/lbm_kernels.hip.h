@@ -511,7 +511,6 @@ struct Step2Args {
   float omega, a1, a2;
   float* partials1;  // per wave: sum |u| after step t   (own cells only)
   float* partials2;  // per wave: sum |u| after step t+1
-  int stagger;       // start delay per resident-wave slot, in units of s_sleep 127 (~8128 clocks); 0 = none
 };
 
 constexpr int kStripQuads = 62;  // output lanes per wave (lanes 1..62; each owns C cells)
@@ -580,12 +579,6 @@ __global__ __launch_bounds__(64) void step2_stream(const Step2Args a) {
   const int lane = threadIdx.x;
   const int strip = blockIdx.x % a.n_strips;
   const int units_x = a.nx / C;
-  if (a.stagger) {
-    // waves that share a SIMD and start together stay in lockstep (all wait for their loads, then all
-    // compute): offset them by their slot on the SIMD so that one computes while the others wait
-    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_ID.wave_id
-    for (unsigned i = 0; i < (slot % 3u) * (unsigned)a.stagger; i++) __builtin_amdgcn_s_sleep(127);
-  }
   const int y0 = a.row_first + (int)(blockIdx.x / a.n_strips) * a.band_pitch;
   const int band_n = min(a.band_rows, a.row_end - y0);
 
