@@ -1193,7 +1193,7 @@ StreamPlan plan_stream(const lbm_params* params, int parts, bool halo_on, int ma
   // Across slabs / ranks a pass costs one exchange and ~10 runtime calls per slab whatever it computes, so
   // several timesteps per pass always pay there (1024^2 over 2/4/8 slabs on one device: 45/74/97 us per step
   // vs 70/113/125 one-step; 2048^2 over 8: 96 vs 261).
-  pl.fuse2 = (pl.vec4 && env_int("LBM_FUSE2", (min_cells >= 560L * 1024 || halo_on) ? 1 : 0)) ? 1 : 0;
+  pl.fuse2 = (pl.vec4 && env_int("LBM_FUSE2", (min_cells >= 300L * 1024 || halo_on) ? 1 : 0)) ? 1 : 0;
   pl.lane_cells = env_int("LBM_LANE_CELLS", min_cells >= 3L * 512 * 1024 ? 4 : 2) == 2 ? 2 : 4;  // from 1.5 Mi cells
   // Timesteps per pass of the stream kernel.  The two-step kernel at 8192^2 is bound by DRAM traffic (round-2 PMC:
   // 5.4-5.8 TB/s at the memory controllers whatever the band height or the arithmetic), so the 4-cell form runs more
@@ -1319,12 +1319,13 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
     if (sl.blocks_main + sl.blocks_boundary > max_blocks) max_blocks = sl.blocks_main + sl.blocks_boundary;
   }
   // ---- which kernel, and its geometry (all measured on MI355X; profiles/r01_tuning.md) --------
-  //   single periodic slab below 560 Ki cells: LDS tiles, 4 or 3 timesteps per launch (step_tile; set further
+  //   single periodic slab below 300 Ki cells (round 2: the packed two-cell stream kernel wins from 576^2 on: 6.0 vs 7.2 us,
+  //                        640^2 7.2 vs 8.9, 704^2 7.2 vs 9.1; 512^2 5.8 vs 5.4): LDS tiles, 4 or 3 timesteps per launch (step_tile; set further
   //                        down).  With halos: two timesteps per pass (half the exchanges).
   //   (one timestep per pass, step_vec4 / step_scalar: the odd last step of a run, widths that are not a multiple
   //                        of 4, LBM_FUSE2=0; it was the default up to 1.5 Mi cells until the two-step kernel stopped
   //                        computing |u| on its warm-up rows: 768^2 9.8 vs 11.3 us, 1024^2 12.35 vs 13.23, 1152^2 15.3 vs 18.1)
-  //   0.56 .. 1.5 Mi cells : two timesteps per pass, 2 cells per lane (one pair: 93-102 VGPRs, 4-5 waves/SIMD, twice
+  //   0.3 .. 1.5 Mi cells : two timesteps per pass, 2 cells per lane (one pair: 93-102 VGPRs, 4-5 waves/SIMD, twice
   //                        the waves of the 4-cell form; packed arithmetic 768^2 7.9 vs 8.7 us, 1024^2 10.7 vs 11.0)
   //   >= 1.5 Mi cells    : FOUR timesteps per pass on pairs of cells, 4 cells per lane (16-byte accesses; us per step,
   //                        this form | 2-cell two-step: 1024^2 15.1 | 10.7, 1280^2 15.2 | 17.2, 1536^2 20.9 | 22.1,
@@ -1423,7 +1424,7 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
     const bool other_kernel_requested = getenv("LBM_FUSE2") || getenv("LBM_VEC4");
     const long cells = (long)params->nx * params->ny;
     const int dflt_shape = (cells <= 200L * 1024) ? 0 : 3;
-    const int dflt_steps = (other_kernel_requested || cells >= 560L * 1024) ? 0 : kTileShapes[dflt_shape].kmax;
+    const int dflt_steps = (other_kernel_requested || cells >= 300L * 1024) ? 0 : kTileShapes[dflt_shape].kmax;
     c->tile_steps = env_int("LBM_TILE_STEPS", dflt_steps);
     c->tile_shape = env_int("LBM_TILE_SHAPE", getenv("LBM_TILE_STEPS") ? (c->tile_steps > 4 ? 1 : 0) : dflt_shape);
     if (c->tile_shape < 0 || c->tile_shape >= kTileShapeCount) c->tile_shape = 0;
