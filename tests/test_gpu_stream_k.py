@@ -24,8 +24,14 @@ def force_stream(monkeypatch, k, band, prefetch=0, chunk=0, stepk=1, packed=None
     monkeypatch.setenv("LBM_STEPK", str(stepk))
 
 
-@pytest.mark.parametrize("k,packed", [(2, 0), (3, 0), (4, 0), (2, 1), (3, 1), (4, 1), (2, 11), (3, 12), (4, 11), (4, 12)])
-@pytest.mark.parametrize("band,prefetch,chunk", [(2, 0, 0), (7, 1, 0), (5, 0, 3), (64, 1, 1), (3, 1, 2)])
+# (timesteps per pass, arithmetic: 0 scalar / 1 pairs / 11, 12 pairs with 1, 2 windows in LDS, band height, prefetch, XCD chunk)
+STREAM_VARIANTS = [(2, 0, 2, 0, 0), (2, 0, 7, 1, 3), (3, 0, 5, 0, 3), (3, 0, 64, 1, 1), (4, 0, 3, 0, 2), (4, 0, 7, 1, 0),
+                   (2, 1, 3, 1, 2), (2, 11, 5, 0, 0), (3, 1, 2, 0, 0), (3, 1, 7, 1, 0), (3, 12, 5, 0, 3), (3, 12, 64, 1, 1),
+                   (4, 1, 2, 0, 0), (4, 1, 5, 0, 3), (4, 11, 7, 1, 0), (4, 11, 3, 0, 2), (4, 12, 2, 1, 0), (4, 12, 7, 1, 0),
+                   (4, 12, 64, 1, 1), (4, 12, 5, 1, 3)]
+
+
+@pytest.mark.parametrize("k,packed,band,prefetch,chunk", STREAM_VARIANTS)
 @pytest.mark.parametrize("slabs,halo", [(1, None), (1, "rccl"), (2, "memcpy"), (3, "memcpy"), (8, "memcpy")])
 def test_k_steps_per_pass_bitwise(lbm, oracle, datasets, monkeypatch, k, packed, band, prefetch, chunk, slabs, halo):
     """Reference data set 128x256 (periodic wrap in y live, wall row in the middle); 76 = 25 three-step passes
