@@ -263,9 +263,11 @@ def main():
         launch_ms = kernel_ms * spl
         achieved = compulsory_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
         pmc = pmc_record(nx, ny, args.math, info) if world == 1 else None
-        kernel_name = {3: "lbm::step3_stream", 2: "lbm::step2_stream", 1: "lbm::step_vec4"}.get(spl, "lbm::step_tile")
-        if info["lane_cells"] == 0 and spl > 1:
-            kernel_name = "lbm::step_tile"
+        if info["lane_cells"] > 0:      # a stream kernel: several timesteps per pass
+            kernel_name = ("lbm::stepk_pk" if args.math == "exact" else
+                           ("lbm::stepk_stream" if info["lane_cells"] == 4 else "lbm::step2_stream"))
+        else:
+            kernel_name = "lbm::step_vec4" if spl == 1 else "lbm::step_tile"
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc.get("traffic_bytes_per_launch") if pmc else None,
