@@ -396,12 +396,12 @@ int launch_stepk(lbm_ctx* c, int s, hipStream_t stream, int k, int row_first, in
   static const fn table[2][2][3][2] = {{LBM_K_ROW(0, false), LBM_K_ROW(0, true)}, {LBM_K_ROW(1, false), LBM_K_ROW(1, true)}};
 #undef LBM_K_ROW
   // exact arithmetic on pairs of cells (v_pk_* instructions): [nontemporal stores][k - 2][prefetch][windows in LDS]
-#define LBM_PK(N, KK, PF, Q) {lbm::stepk_pk<N, KK, PF, 0, Q>, lbm::stepk_pk<N, KK, PF, 1, Q>, lbm::stepk_pk<N, KK, PF, (KK > 2 ? 2 : 1), Q>}
-#define LBM_PK_ROW(N, Q) {{LBM_PK(N, 2, false, Q), LBM_PK(N, 2, true, Q)}, {LBM_PK(N, 3, false, Q), LBM_PK(N, 3, true, Q)}, \
-                          {LBM_PK(N, 4, false, Q), LBM_PK(N, 4, true, Q)}}
-  // [both pairs in one block][nontemporal stores][k - 2][prefetch][windows in LDS]
-  static const fn table_pk[2][2][3][2][3] = {{LBM_PK_ROW(false, false), LBM_PK_ROW(true, false)},
-                                             {LBM_PK_ROW(false, true), LBM_PK_ROW(true, true)}};
+#define LBM_PK(N, KK, PF) {lbm::stepk_pk<N, KK, PF, 0>, lbm::stepk_pk<N, KK, PF, 1>, lbm::stepk_pk<N, KK, PF, (KK > 2 ? 2 : 1)>}
+#define LBM_PK_ROW(N) {{LBM_PK(N, 2, false), LBM_PK(N, 2, true)}, {LBM_PK(N, 3, false), LBM_PK(N, 3, true)}, \
+                       {LBM_PK(N, 4, false), LBM_PK(N, 4, true)}}
+  // [nontemporal stores][k - 2][prefetch][windows in LDS]  (the QUAD form of stepk_pk -- both pairs of a lane in one
+  // basic block -- measured the same speed with more registers and is not instantiated: profiles/r02_tuning.md)
+  static const fn table_pk[2][3][2][3] = {LBM_PK_ROW(false), LBM_PK_ROW(true)};
 #undef LBM_PK_ROW
 #undef LBM_PK
   // two cells per lane: one pair, two steps per pass: [nontemporal stores][prefetch][windows in LDS]
@@ -413,7 +413,7 @@ int launch_stepk(lbm_ctx* c, int s, hipStream_t stream, int k, int row_first, in
   const int lds_windows = c->lds_windows < k ? c->lds_windows : k - 1;
   const bool packed = c->packed && c->math_mode == LBM_MATH_EXACT;
   const fn kernel = (packed && c->lane_cells == 2) ? table_pk1[c->nts][c->prefetch ? 1 : 0][lds_windows ? 1 : 0]
-                    : packed ? table_pk[c->packed == 2 ? 1 : 0][c->nts][k - 2][c->prefetch ? 1 : 0][lds_windows]
+                    : packed ? table_pk[c->nts][k - 2][c->prefetch ? 1 : 0][lds_windows]
                            : table[c->math_mode == LBM_MATH_EXACT ? 0 : 1][c->nts][k - 2][c->prefetch ? 1 : 0];
   if (done) hipExtLaunchKernelGGL(kernel, dim3(waves), dim3(64), 0, stream, nullptr, done, 0, a);
   else hipLaunchKernelGGL(kernel, dim3(waves), dim3(64), 0, stream, a);
@@ -1342,9 +1342,8 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
   // without prefetch / LDS | scalar K = 3: 16384^2 1091 | 1097 | 1355, 12288^2 640 | 652 | 838, 6144^2 180 | 187 | 233,
   // 4096^2 75.3 | 78.1 | 94.7, 3072^2 45.6 | 45.3 | 59.0, 2048^2 24.9 | 26.3 | 31.9; a rank's share through the halo
   // pipeline 8192x1024 45.1 | 46.7 | 55.3, 8192x2048 77.5 | 81.4 | 98.9, 8192x4096 149 | 152 | 187.
-  c->packed = env_int("LBM_PACKED", math_mode == LBM_MATH_EXACT ? 1 : 0);  // 2: both pairs in one block (4 cells)
-  if (c->lane_cells == 2 && c->packed == 2) c->packed = 1;
-  if (c->packed < 0 || c->packed > 2 || math_mode != LBM_MATH_EXACT) c->packed = 0;
+  c->packed = env_int("LBM_PACKED", math_mode == LBM_MATH_EXACT ? 1 : 0) ? 1 : 0;
+  if (math_mode != LBM_MATH_EXACT) c->packed = 0;
   c->lds_windows = env_int("LBM_LDS_WINDOWS", (c->packed && c->pass_steps == 4) ? 2 : 0);
   if (c->lds_windows < 0 || c->lds_windows > 2 || !c->packed) c->lds_windows = 0;
   // scalar K = 4 with prefetch spills (245 + 36 VGPRs); the packed K = 4 needs its LDS windows for it
