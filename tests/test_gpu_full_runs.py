@@ -61,6 +61,31 @@ def test_cli_full_run_matches_serialcode_bytes_and_goldens(lbm, tmp_path, name):
         assert lbm.check_passes(gold[f"pressure_{name}"], pr)
 
 
+@pytest.mark.parametrize("name,env", [
+    ("1024x1024", {"LBM_FUSE2": "1", "LBM_LANE_CELLS": "4"}),                            # four steps on pairs, 2 LDS windows
+    ("256x256", {"LBM_FUSE2": "1", "LBM_LANE_CELLS": "4"}),
+    ("128x256", {"LBM_FUSE2": "1", "LBM_LANE_CELLS": "4", "LBM_PASS_STEPS": "3"}),       # three steps on pairs
+    ("1024x1024", {"LBM_FUSE2": "1", "LBM_LANE_CELLS": "4", "LBM_PACKED": "0", "LBM_PASS_STEPS": "3"}),   # scalar stream kernel
+    ("256x256", {"LBM_FUSE2": "1", "LBM_LANE_CELLS": "2"}),                              # two steps, one pair per lane
+    ("128x128", {"LBM_FUSE2": "1", "LBM_LANE_CELLS": "4", "LBM_GPUS": "4", "LBM_HALO": "memcpy"}),   # 4-row halos, 32-row slabs
+])
+def test_cli_large_grid_kernels_full_run_match_serialcode_bytes(lbm, tmp_path, name, env):
+    """The kernels that large grids get by default (and their A/B alternatives), forced onto the reference's data sets:
+    at the reference's full iteration counts (20 000 - 80 000 dependent steps) `final_state.dat` must still be the
+    SerialCode binary's, byte for byte -- the strongest parity statement the reference's own outputs allow for the
+    headline kernel."""
+    pf = os.path.join(GOLDEN, "inputs", f"input_{name}.params")
+    of = os.path.join(GOLDEN, "inputs", f"obstacles_{name}.dat")
+    out = subprocess.run([lbm.CLI_PATH, pf, of], cwd=tmp_path, capture_output=True, text=True, env=dict(os.environ, **env))
+    assert out.returncode == 0, out.stderr
+    ref = np.load(os.path.join(GOLDEN, f"serialcode_{name}.npz"))
+    assert md5(tmp_path / "final_state.dat") == str(ref["md5_final_state"])
+    av = np.loadtxt(tmp_path / "av_vels.dat", usecols=[1])
+    np.testing.assert_allclose(av, ref["av_vels"].astype(np.float64), rtol=5e-4)
+    gold = np.load(os.path.join(GOLDEN, "check_goldens.npz"))
+    assert lbm.check_passes(gold[f"av_vels_{name}"], av)
+
+
 @pytest.mark.parametrize("name,gpus,fuse", [("128x256", "4", "0"), ("256x256", "3", "1"), ("1024x1024", "8", "1")])
 def test_cli_multi_slab_full_run_matches_serialcode_bytes(lbm, tmp_path, name, gpus, fuse):
     """The command line with LBM_GPUS row slabs (here sharing the one device, halos by device copies):
