@@ -237,6 +237,7 @@ struct lbm_ctx {
   int xcd_chunk = 0;   // stream kernel: strips per XCD chunk (LBM_XCD_CHUNK; 0 = plain workgroup order)
   int use_stepk = 0;   // two-step passes through stepk_stream<K=2> instead of step2_stream (LBM_STEPK; experiments)
   int packed = 0;      // stream kernel: collision on pairs of cells, v_pk_* instructions (LBM_PACKED)
+  int halo_lanes = 1;  // stream kernel: lanes at each end of a wave that only feed their neighbours
   int lds_windows = 0; // packed stream kernel: how many of the K-1 sliding windows live in LDS (LBM_LDS_WINDOWS, 0..2)
   int band_rows = 8, n_strips = 0;  // step2_stream geometry: band height, waves across x
   int lane_cells = 4;               // cells per lane in step2_stream (4 or 2; LBM_LANE_CELLS)
@@ -375,6 +376,7 @@ int launch_stepk(lbm_ctx* c, int s, hipStream_t stream, int k, int row_first, in
   a.n_strips = c->n_strips;
   a.n_bands = band_count;
   a.chunk = c->xcd_chunk;
+  a.halo_lanes = c->halo_lanes;
   a.accel_row = sl.accel_row;
   a.accel_row2 = sl.accel_row2;
   a.accel_after = accel_after ? 1 : 0;
@@ -404,15 +406,16 @@ int launch_stepk(lbm_ctx* c, int s, hipStream_t stream, int k, int row_first, in
   static const fn table_pk[2][3][2][3] = {LBM_PK_ROW(false), LBM_PK_ROW(true)};
 #undef LBM_PK_ROW
 #undef LBM_PK
-  // two cells per lane: one pair, two steps per pass: [nontemporal stores][prefetch][windows in LDS]
-  static const fn table_pk1[2][2][2] = {
-      {{lbm::stepk_pk<false, 2, false, 0, false, 1>, lbm::stepk_pk<false, 2, false, 1, false, 1>},
-       {lbm::stepk_pk<false, 2, true, 0, false, 1>, lbm::stepk_pk<false, 2, true, 1, false, 1>}},
-      {{lbm::stepk_pk<true, 2, false, 0, false, 1>, lbm::stepk_pk<true, 2, false, 1, false, 1>},
-       {lbm::stepk_pk<true, 2, true, 0, false, 1>, lbm::stepk_pk<true, 2, true, 1, false, 1>}}};
+  // two cells per lane (one pair): [nontemporal stores][k - 2][prefetch][windows in LDS: 0, 1]
+#define LBM_PK1(N, KK, PF) {lbm::stepk_pk<N, KK, PF, 0, false, 1>, lbm::stepk_pk<N, KK, PF, 1, false, 1>}
+#define LBM_PK1_ROW(N) {{LBM_PK1(N, 2, false), LBM_PK1(N, 2, true)}, {LBM_PK1(N, 3, false), LBM_PK1(N, 3, true)}, \
+                        {LBM_PK1(N, 4, false), LBM_PK1(N, 4, true)}}
+  static const fn table_pk1[2][3][2][2] = {LBM_PK1_ROW(false), LBM_PK1_ROW(true)};
+#undef LBM_PK1_ROW
+#undef LBM_PK1
   const int lds_windows = c->lds_windows < k ? c->lds_windows : k - 1;
   const bool packed = c->packed && c->math_mode == LBM_MATH_EXACT;
-  const fn kernel = (packed && c->lane_cells == 2) ? table_pk1[c->nts][c->prefetch ? 1 : 0][lds_windows ? 1 : 0]
+  const fn kernel = (packed && c->lane_cells == 2) ? table_pk1[c->nts][k - 2][c->prefetch ? 1 : 0][lds_windows ? 1 : 0]
                     : packed ? table_pk[c->nts][k - 2][c->prefetch ? 1 : 0][lds_windows]
                            : table[c->math_mode == LBM_MATH_EXACT ? 0 : 1][c->nts][k - 2][c->prefetch ? 1 : 0];
   if (done) hipExtLaunchKernelGGL(kernel, dim3(waves), dim3(64), 0, stream, nullptr, done, 0, a);
@@ -425,7 +428,7 @@ int launch_stepk(lbm_ctx* c, int s, hipStream_t stream, int k, int row_first, in
 int launch_pass(lbm_ctx* c, int s, hipStream_t stream, int k, int row_first, int row_end, int band_rows,
                 int band_pitch, int band_count, int part_offset, bool accel_after, hipEvent_t done = nullptr) {
   if ((c->lane_cells == 4 && (k > 2 || c->prefetch || c->xcd_chunk || c->use_stepk || c->packed)) ||
-      (c->lane_cells == 2 && k == 2 && c->packed && c->math_mode == LBM_MATH_EXACT))
+      (c->lane_cells == 2 && c->packed && c->math_mode == LBM_MATH_EXACT))
     return launch_stepk(c, s, stream, k, row_first, row_end, band_rows, band_pitch, band_count, part_offset, accel_after, done);
   return launch_step2(c, s, stream, row_first, row_end, band_rows, band_pitch, band_count, part_offset, accel_after, done);
 }
@@ -1194,15 +1197,21 @@ StreamPlan plan_stream(const lbm_params* params, int parts, bool halo_on, int ma
   // several timesteps per pass always pay there (1024^2 over 2/4/8 slabs on one device: 45/74/97 us per step
   // vs 70/113/125 one-step; 2048^2 over 8: 96 vs 261).
   pl.fuse2 = (pl.vec4 && env_int("LBM_FUSE2", (min_cells >= 300L * 1024 || halo_on) ? 1 : 0)) ? 1 : 0;
-  pl.lane_cells = env_int("LBM_LANE_CELLS", min_cells >= 3L * 512 * 1024 ? 4 : 2) == 2 ? 2 : 4;  // from 1.5 Mi cells
+  pl.lane_cells = env_int("LBM_LANE_CELLS", min_cells >= 7L * 512 * 1024 ? 4 : 2) == 2 ? 2 : 4;  // from 3.5 Mi cells
   // Timesteps per pass of the stream kernel.  The two-step kernel at 8192^2 is bound by DRAM traffic (round-2 PMC:
   // 5.4-5.8 TB/s at the memory controllers whatever the band height or the arithmetic), so the 4-cell form runs more
   // steps per pass: K = 3 (stepk_stream, 2 waves per SIMD, next row prefetched) 0.345 vs 0.47-0.49 ms per step, at
   // which point it is bound by VALU issue again (K = 4 with scalar arithmetic: 0.36); with the collision on PAIRS of
   // cells (stepk_pk: v_pk_* instructions, 108 instead of 155 lane-instructions per update) K = 4 pays: 0.275-0.285.
   // The packed kernel exists for the exact arithmetic only; the 2-cell form for K = 2 only.
-  pl.pass_steps = env_int("LBM_PASS_STEPS", pl.lane_cells == 4 ? (math_mode == LBM_MATH_EXACT ? 4 : 3) : 2);
-  if (pl.pass_steps < 2 || pl.pass_steps > kHaloRows || pl.lane_cells != 4) pl.pass_steps = 2;
+  // The two-cell form (one pair per lane, twice the waves: mid-size grids) takes two halo lanes per side beyond two
+  // steps and runs K = 3 as the packed kernel (124 VGPRs, 4 waves per SIMD): 1024^2 9.4 vs 10.7 us (K = 2), 1280^2
+  // 12.4 vs 15.2 (four-cell K = 4), 1536^2 15.2 vs 20.9, 1792^2 20.2 vs 22.3; from 2048^2 the four-cell form wins
+  // (24.9 vs 25.6-27.5).
+  const bool exact_packed = (math_mode == LBM_MATH_EXACT) && env_int("LBM_PACKED", 1) != 0;
+  pl.pass_steps = env_int("LBM_PASS_STEPS", pl.lane_cells == 4 ? (math_mode == LBM_MATH_EXACT ? 4 : 3) : (exact_packed ? 3 : 2));
+  if (pl.pass_steps < 2 || pl.pass_steps > kHaloRows) pl.pass_steps = 2;
+  if (pl.lane_cells != 4 && !exact_packed) pl.pass_steps = 2;  // the scalar two-cell kernel (step2_stream) is two-step
   // across slabs a K-step pass needs slabs of at least 2K rows (the stream kernel at all: 4); a periodic slab at least K
   if (halo_on && min_rows < 2 * pl.pass_steps) pl.pass_steps = 2;
   if (halo_on && min_rows < 4) pl.fuse2 = 0;
@@ -1325,9 +1334,9 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
   //   (one timestep per pass, step_vec4 / step_scalar: the odd last step of a run, widths that are not a multiple
   //                        of 4, LBM_FUSE2=0; it was the default up to 1.5 Mi cells until the two-step kernel stopped
   //                        computing |u| on its warm-up rows: 768^2 9.8 vs 11.3 us, 1024^2 12.35 vs 13.23, 1152^2 15.3 vs 18.1)
-  //   0.3 .. 1.5 Mi cells : two timesteps per pass, 2 cells per lane (one pair: 93-102 VGPRs, 4-5 waves/SIMD, twice
-  //                        the waves of the 4-cell form; packed arithmetic 768^2 7.9 vs 8.7 us, 1024^2 10.7 vs 11.0)
-  //   >= 1.5 Mi cells    : FOUR timesteps per pass on pairs of cells, 4 cells per lane (16-byte accesses; us per step,
+  //   0.3 .. 3.5 Mi cells : THREE timesteps per pass, 2 cells per lane (one pair, two halo lanes per side: 124 VGPRs,
+  //                        4 waves/SIMD, twice the waves of the 4-cell form; 1024^2 9.4 us vs 10.7 two-step)
+  //   >= 3.5 Mi cells    : FOUR timesteps per pass on pairs of cells, 4 cells per lane (16-byte accesses; us per step,
   //                        this form | 2-cell two-step: 1024^2 15.1 | 10.7, 1280^2 15.2 | 17.2, 1536^2 20.9 | 22.1,
   //                        1792^2 22.1 | 28.2; three-step scalar | two-step: 2048^2 31.8 | 35.4, 3072^2 59.0 | 76.0,
   //                        4096^2 93 | 129, 8192^2 340 | 492; four-step packed: 2048^2 24.9, 4096^2 75.3, 8192^2 277-285)
@@ -1335,8 +1344,9 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
   // every rank of a multi-process run takes the same path.
   c->fuse2 = plan.fuse2;
   c->lane_cells = plan.lane_cells;
-  c->n_strips = ceil_div(params->nx / c->lane_cells > 0 ? params->nx / c->lane_cells : 1, lbm::kStripQuads);
   c->pass_steps = plan.pass_steps;
+  c->halo_lanes = ceil_div(c->pass_steps, c->lane_cells);
+  c->n_strips = ceil_div(params->nx / c->lane_cells > 0 ? params->nx / c->lane_cells : 1, 64 - 2 * c->halo_lanes);
   // Packed arithmetic (exact mode, 4 cells per lane): on.  With K = 4 two of the three sliding windows live in LDS
   // (18 KB per wave), which leaves registers to prefetch the next row (216 VGPRs): us per step, this form | packed
   // without prefetch / LDS | scalar K = 3: 16384^2 1091 | 1097 | 1355, 12288^2 640 | 652 | 838, 6144^2 180 | 187 | 233,
@@ -1347,7 +1357,7 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
   c->lds_windows = env_int("LBM_LDS_WINDOWS", (c->packed && c->pass_steps == 4) ? 2 : 0);
   if (c->lds_windows < 0 || c->lds_windows > 2 || !c->packed) c->lds_windows = 0;
   // scalar K = 4 with prefetch spills (245 + 36 VGPRs); the packed K = 4 needs its LDS windows for it
-  c->prefetch = env_int("LBM_PREFETCH", (c->pass_steps == 3 || (c->pass_steps == 4 && c->lds_windows == 2)) ? 1 : 0) ? 1 : 0;
+  c->prefetch = env_int("LBM_PREFETCH", (c->lane_cells == 4 && (c->pass_steps == 3 || (c->pass_steps == 4 && c->lds_windows == 2))) ? 1 : 0) ? 1 : 0;
   // strips per XCD chunk: a whole band of strips, for slabs of many rounds of waves only (16384^2, K = 4: 1.033 ms per
   // step with 67-strip chunks, 1.088 with 34, 1.107 without; K = 3: 12288^2 0.793 vs 0.832).  Elsewhere the band height
   // packs the waves tightly into rounds (below) and the few empty workgroups of the chunked order spill into an
@@ -1381,6 +1391,14 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
         const long cost = rounds * (b + 2);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; pick = (int)b; }
       }
+    }
+    if (c->lane_cells == 2 && c->pass_steps >= 3) {
+      // two-cell packed kernel: these sizes are bound by latency, and the best height is the one that spreads the
+      // slab over one round of two waves per SIMD (2048 waves): 768^2 3, 1024^2 5, 1152^2 6, 1280^2 7-8, 1536^2 10,
+      // 1792^2 14-16 rows (profiles/r02_tuning.md)
+      const long interior = (n_slabs > 1 || world > 1 || halo_on) ? rows_eff + 4 - 2 * c->pass_steps : rows_eff;
+      long b = ((interior > 1 ? interior : 1) * c->n_strips + 2047) / 2048;
+      pick = (int)(b < 3 ? 3 : (b > 64 ? 64 : b));
     }
     if (c->lane_cells == 4 && c->pass_steps >= 3) {
       // K >= 3 (2 waves per SIMD, bound by instruction issue): the waves run in rounds of 2048 and every wave of a round

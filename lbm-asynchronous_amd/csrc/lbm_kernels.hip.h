@@ -736,6 +736,7 @@ struct StepKArgs {
   int n_strips;    // waves across x
   int n_bands;     // bands of this launch
   int chunk;       // strips per XCD chunk (0: plain order, strip fastest)
+  int halo_lanes;  // lanes at each end of a wave that only feed their neighbours: ceil(K / cells per lane) of the context
   int accel_row;
   int accel_row2;  // a second periodic image of the lid row among the halo rows, or kNoRow
   int accel_after;
@@ -775,11 +776,12 @@ __global__ __launch_bounds__(64, (K >= 3 || PREFETCH) ? 2 : 3) void stepk_stream
   const int y0 = a.row_first + band * a.band_pitch;
   const int band_n = min(a.band_rows, a.row_end - y0);
 
-  const int ux_raw = strip * kStripQuads + lane - 1;
+  const int H = a.halo_lanes;  // H * C >= K cells of halo per side
+  const int ux_raw = strip * (64 - 2 * H) + lane - H;
   int ux = ux_raw % units_x;
   if (ux < 0) ux += units_x;
   const int x0 = ux * C;
-  const bool out_lane = (lane >= 1) && (lane <= kStripQuads) && (ux_raw < units_x);
+  const bool out_lane = (lane >= H) && (lane < 64 - H) && (ux_raw < units_x);
   const long ps = a.plane_stride;
 
   Step2Args pa;  // pull_row's view of the arguments
@@ -1078,8 +1080,8 @@ struct WindowPk {
 // NP = pairs per lane: 2 (four cells, 16-byte accesses, K <= 4) or 1 (two cells, 8-byte accesses, K <= 2: a halo lane's
 // two cells cover two steps) -- the form for grids too small to fill the chip with four-cell lanes.
 template <bool NTS, int K, bool PREFETCH, int LW, bool QUAD = false, int NP = 2>
-__global__ __launch_bounds__(64, (NP == 1 && !PREFETCH) ? 4 : 2) void stepk_pk(const StepKArgs a) {
-  static_assert(K >= 2 && K <= 2 * NP && LW >= 0 && LW <= K - 1 && (NP == 2 || !QUAD), "one halo lane per side covers K <= C steps");
+__global__ __launch_bounds__(64, NP == 1 ? (K > 2 ? 3 : (PREFETCH ? 2 : 4)) : 2) void stepk_pk(const StepKArgs a) {
+  static_assert(K >= 2 && K <= 4 && LW >= 0 && LW <= K - 1 && (NP == 2 || !QUAD), "halo_lanes * C >= K is the host's job");
   constexpr int C = 2 * NP;
   typedef typename RowPull<C>::vec vec;
   __shared__ vec lds_win[LW > 0 ? LW : 1][9][64];
@@ -1101,11 +1103,12 @@ __global__ __launch_bounds__(64, (NP == 1 && !PREFETCH) ? 4 : 2) void stepk_pk(c
   const int y0 = a.row_first + band * a.band_pitch;
   const int band_n = min(a.band_rows, a.row_end - y0);
 
-  const int ux_raw = strip * kStripQuads + lane - 1;
+  const int H = a.halo_lanes;  // H * C >= K cells of halo per side
+  const int ux_raw = strip * (64 - 2 * H) + lane - H;
   int ux = ux_raw % units_x;
   if (ux < 0) ux += units_x;
   const int x0 = ux * C;
-  const bool out_lane = (lane >= 1) && (lane <= kStripQuads) && (ux_raw < units_x);
+  const bool out_lane = (lane >= H) && (lane < 64 - H) && (ux_raw < units_x);
   const long ps = a.plane_stride;
 
   Step2Args pa;

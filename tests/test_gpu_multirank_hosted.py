@@ -85,12 +85,13 @@ FOUR_STEP = {"LBM_FUSE2": "1", "LBM_LANE_CELLS": "4"}
 
 
 @pytest.mark.parametrize("world,case,steps_list,env,depth", [
-    (2, "128x256", [75], None, 2),                     # two-step passes, odd tail
-    (3, "128x256", [40, 1, 22], None, 2),              # run in pieces
+    (2, "128x256", [76], None, 3),                     # default at this size: three-step passes on one pair per lane
+    (3, "128x256", [40, 1, 22], None, 3),              # run in pieces
+    (2, "128x256", [75], {"LBM_PASS_STEPS": "2"}, 2),  # two-step passes, odd tail
     (2, "128x256", [77], FOUR_STEP, 4),                # four-step packed passes + a one-step tail; 2 ranks: north == south
     (3, "128x256", [31, 2, 44], FOUR_STEP, 4),
     (3, (512, 50, 5), [26], FOUR_STEP, 4),             # random lattice, uneven slabs (17, 17, 16 rows), both wraps live
-    (2, (260, 33, 6), [9], None, 2),                   # 4 | nx but nx % 64 != 0
+    (2, (260, 33, 6), [9], None, 3),                   # 4 | nx but nx % 64 != 0
 ])
 def test_hosted_ranks_equal_single_domain(tmp_path, oracle, lbm, world, case, steps_list, env, depth):
     torch.set_num_threads(1)

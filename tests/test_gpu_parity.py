@@ -444,9 +444,9 @@ def test_lds_tile_shapes_bitwise(lbm, oracle, monkeypatch, shape, steps):
 
 
 def test_default_kernel_by_grid_size(lbm, datasets):
-    """The policy of DESIGN.md section 6: LDS tiles below 300 Ki cells, two steps per pass (two cells per lane) from
-    there, four steps per pass (four cells per lane, packed arithmetic) from 1.5 Mi cells."""
-    for n, want in ((128, 4), (448, 4), (512, 3), (576, 2), (640, 2), (768, 2), (1024, 2), (1280, 4), (2048, 4)):
+    """The policy of DESIGN.md section 6: LDS tiles below 300 Ki cells, three steps per pass on one pair of cells per
+    lane from there, four steps per pass on two pairs per lane from 3.5 Mi cells."""
+    for n, want in ((128, 4), (448, 4), (512, 3), (576, 3), (768, 3), (1024, 3), (1792, 3), (1920, 4), (2048, 4)):
         p = lbm.Params(n, n, 4, 10, 0.1, 0.005, 1.85)
         ob = np.zeros((n, n), dtype=np.int32)
         with lbm.Engine(p, ob, None) as eng:

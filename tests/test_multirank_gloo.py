@@ -3,7 +3,7 @@
 The GPU engine shards the grid by rows, one slab per rank, keeps halo rows around every slab
 and, once per pass, ships WHOLE boundary rows to its ring neighbours (lbm_hip.hip: exchange_halos --
 the GPU analogue of /root/reference/MPI_Waitall/d2q9-bgk.c:225-253); a pass advances K timesteps
-(K = 2 or 3: the stream kernels, halo depth K), else one.  RCCL needs one GPU per rank, which
+(K = 2, 3 or 4: the stream kernels, halo depth K), else one.  RCCL needs one GPU per rank, which
 the builder container and the 1-GPU box lack, so this test replays the SAME protocol on CPU ranks,
 with the bookkeeping taken from the product so the replay cannot drift from the engine:
 
@@ -181,7 +181,8 @@ FOUR_STEP = {"LBM_FUSE2": "1", "LBM_LANE_CELLS": "4"}                           
 THREE_STEP = dict(FOUR_STEP, LBM_PASS_STEPS="3")                                # ... and in the fast-math mode
 
 
-@pytest.mark.parametrize("world,name,steps,env,depth", [(2, "128x128", 61, None, 2), (3, "128x256", 40, None, 2),
+@pytest.mark.parametrize("world,name,steps,env,depth", [(2, "128x128", 61, None, 3), (3, "128x256", 40, None, 3),
+                                                        (2, "128x128", 61, {"LBM_PASS_STEPS": "2"}, 2),
                                                         (2, "128x128", 62, THREE_STEP, 3), (3, "128x256", 43, THREE_STEP, 3),
                                                         (4, "128x256", 31, THREE_STEP, 3), (2, "128x128", 63, FOUR_STEP, 4),
                                                         (3, "128x256", 45, FOUR_STEP, 4)])
