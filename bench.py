@@ -478,6 +478,24 @@ def main():
                 if use_rank_api:
                     break                       # ranks may have diverged: stop issuing collectives
 
+    # the one-timestep-per-pass kernel on the headline grid, measured in the same run: the kernel that IS bound by HBM
+    # bandwidth (72 B per update actually move), beside the temporally blocked one whose limit is instruction issue
+    if world == 1 and not use_rank_api and os.environ.get("LBM_BENCH_ALSO", "1") != "0" and "LBM_FUSE2" not in os.environ:
+        os.environ["LBM_FUSE2"] = "0"
+        try:
+            dt, k_ms, inf, fin, _ = measure(nx, ny, max(args.steps, 20), args.warmup, n_repeats=3)
+            if inf["steps_per_launch"] == 1 and k_ms > 0:
+                gbps = BYTES_PER_UPDATE * nx * ny / (k_ms * 1e-3) / 1e9
+                also["one_step_kernel"] = {"kernel": "lbm::step_vec4", "grid": f"{nx}x{ny}", "ms_per_step": dt / max(args.steps, 20) * 1e3,
+                                           "kernel_ms_per_step": k_ms, "value": nx * ny / (k_ms * 1e-3) / 1e6, "unit": "MLUPS",
+                                           "achieved_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBS, "bound": "hbm",
+                                           "results_finite": fin,
+                                           "note": "LBM_FUSE2=0: one timestep per pass, every update moves its 72 B"}
+        except Exception as exc:
+            also["one_step_kernel"] = {"error": str(exc)}
+        finally:
+            os.environ.pop("LBM_FUSE2", None)
+
     watchdog.cancel()
     failed = bool(check) and not check.get("fields_bitwise_equal_to_single_gpu_run", False)
     if rank == 0:
