@@ -1330,7 +1330,7 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
   // ---- which kernel, and its geometry (all measured on MI355X; profiles/r01_tuning.md) --------
   //   single periodic slab below 300 Ki cells (round 2: the packed two-cell stream kernel wins from 576^2 on: 6.0 vs 7.2 us,
   //                        640^2 7.2 vs 8.9, 704^2 7.2 vs 9.1; 512^2 5.8 vs 5.4): LDS tiles, 4 or 3 timesteps per launch (step_tile; set further
-  //                        down).  With halos: two timesteps per pass (half the exchanges).
+  //                        down).  With halos: always several timesteps per pass (fewer exchanges).
   //   (one timestep per pass, step_vec4 / step_scalar: the odd last step of a run, widths that are not a multiple
   //                        of 4, LBM_FUSE2=0; it was the default up to 1.5 Mi cells until the two-step kernel stopped
   //                        computing |u| on its warm-up rows: 768^2 9.8 vs 11.3 us, 1024^2 12.35 vs 13.23, 1152^2 15.3 vs 18.1)
