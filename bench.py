@@ -16,7 +16,15 @@ LBM_BENCH_PREWARM_S (0.3 s: a cold GPU clocks up over the first ~0.1 s, which ma
 sides, max over ranks -- LBM_BENCH_REPEATS (5) times back to back; `value`, `ms_per_step` and the
 roofline come from the MEDIAN repeat, every repeat is listed in `repeats_ms_per_step`.
 
-Rank 0 prints ONE JSON line; see the task contract for its keys.  Roofline block: `achieved` is the
+Launching: `python bench.py --gpus N` started WITHOUT a torch.distributed environment (no WORLD_SIZE) launches
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...`
+itself, as a CHILD process, before torch or HIP is touched in this process (never exec), relays the child's
+single JSON line and exit status, and kills the child's process group if it outlives LBM_BENCH_LAUNCH_TIMEOUT
+(default 1500 s) -- then it exits non-zero.  Started by torch.distributed.run (WORLD_SIZE set) it is a rank.
+LBM_BENCH_SELF_LAUNCH=1 takes the child path for --gpus 1 too (rehearsal of the multi-GPU launch on one GPU).
+
+Rank 0 prints ONE JSON line; see the task contract for its keys.  `rccl` in it says which RCCL the engine bound
+(library path, version) and how many ranks its communicator counts -- "did RCCL see N ranks, and which RCCL".  Roofline block: `achieved` is the
 COMPULSORY traffic of one launch of the dominant kernel -- the slab's lattice read once and written
 once, 72 B per cell, however many timesteps the launch advances -- divided by the launch's device
 time (HIP events on the engine's compute stream), so `frac` = achieved / 8 TB/s is a true fraction
@@ -192,6 +200,65 @@ def pmc_record(nx, ny, math, info):
     return rec
 
 
+def self_launch(args):
+    """`bench.py --gpus N` without a torch.distributed environment: run the N ranks under torch.distributed.run as a
+    child process of this one -- nothing in THIS process has imported torch or touched HIP -- relay the one JSON line
+    its rank 0 prints and its exit status.  A watchdog kills the child's process group (its own session) when it
+    outlives the limit; this process then exits non-zero.  Never exec: the GPU boxes forbid replacing a process
+    image, and a parent that stays around is what makes the watchdog possible."""
+    import signal
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, LBM_BENCH_CHILD="1")
+    if args.gpus == 1:
+        env["LBM_BENCH_RANK_API"] = "1"      # a world of one through the rank code path: RCCL communicator of one rank
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL across processes needs dmabuf IPC on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    limit = float(os.environ.get("LBM_BENCH_LAUNCH_TIMEOUT", "1500"))
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True)
+    timed_out = []
+
+    def kill_child():
+        timed_out.append(True)
+        try:
+            os.killpg(child.pid, signal.SIGKILL)     # the exact process group this function started
+        except ProcessLookupError:
+            pass
+
+    timer = threading.Timer(limit, kill_child)
+    timer.daemon = True
+    timer.start()
+    out, _ = child.communicate()
+    timer.cancel()
+    try:
+        os.killpg(child.pid, signal.SIGKILL)         # ranks that outlived the launcher (a hung collective)
+    except (ProcessLookupError, PermissionError):
+        pass
+    lines = [ln for ln in out.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    rc = child.returncode
+    if timed_out:
+        sys.stderr.write(f"bench.py: the {args.gpus}-rank child did not finish within {limit:.0f} s and was killed "
+                         f"(LBM_BENCH_LAUNCH_TIMEOUT)\n")
+        rc = rc or 124
+    if rc == 0 and not lines:
+        sys.stderr.write("bench.py: the child printed no JSON line\n")
+        rc = 6
+    if rc != 0:
+        sys.stderr.write(f"bench.py: the {args.gpus}-rank run failed (exit status {rc}).  If the failure is in the "
+                         f"engine's own multi-GPU issue path rather than in the launch: the one-process-per-GPU form used "
+                         f"here issues from one host thread per rank; the one-process form (host program, LBM_GPUS=n) "
+                         f"uses one issuing thread per slab by default on distinct devices -- LBM_THREADS=0 forces its "
+                         f"single-thread issue path; LBM_RCCL_LIB=<path> selects another librccl.\n")
+    sys.exit(rc if rc >= 0 else 128 - rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,10 +273,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("LBM_BENCH_SELF_LAUNCH") == "1"):
+        self_launch(args)                    # does not return
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 as\n  python -m torch.distributed.run "
-                         f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port 29500 "
-                         f"bench.py --gpus {args.gpus} ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus {args.gpus}` "
+                         f"(it launches its ranks itself) or under torch.distributed.run with --nproc-per-node {args.gpus}")
     repeats = max(1, int(os.environ.get("LBM_BENCH_REPEATS", "5")))
     prewarm_s = float(os.environ.get("LBM_BENCH_PREWARM_S", "0.3"))
 
@@ -225,6 +293,16 @@ def main():
     lbm = load_package()
     if not os.path.exists(lbm.LIB_PATH):
         raise SystemExit("liblbm_hip.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    # device count first (counting does not initialise the GPU): every rank of an over-subscribed launch leaves at
+    # once, with a message, instead of one rank dying inside a collective the others then wait in
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if local_world > n_dev or local_rank >= n_dev:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {local_world} devices on this node, {n_dev} visible "
+                         f"(rank {rank})\n")
+        sys.exit(3)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -304,13 +382,22 @@ def main():
             "config": {"workload": f"D2Q9-BGK timestep loop, {r['workload']}, uniform-equilibrium start",
                        "grid": f"{nx}x{ny}", "math": args.math,
                        "timesteps_per_memory_pass": spl,
-                       "decomposition": f"{world} row slab(s), RCCL halo send/recv" if world > 1
-                       else "single slab, periodic in-kernel"},
+                       "decomposition": (f"{world} row slab(s), one process per GPU, RCCL halo send/recv" if world > 1
+                                         else ("one rank through the rank pipeline: halo rows by RCCL self-exchange, "
+                                               "interior / boundary split" if use_rank_api and os.environ.get("LBM_FORCE_HALO") == "1"
+                                               else ("one rank through the rank API (communicator of one), periodic in-kernel"
+                                                     if use_rank_api else "single slab, periodic in-kernel")))},
             "timing": {"repeats": len(r["repeats"]), "statistic": "median",
                        "repeats_ms_per_step": [e / args.steps * 1e3 for e in r["repeats"]],
                        "prewarm_steps_untimed": r["prewarm_steps"], "prewarm_target_s": prewarm_s},
             "roofline": roof,
             "results_finite": r["finite"],
+            "rccl": dict(r.get("rccl") or {}, torch_backend=("nccl (torch.distributed barrier / reductions of the "
+                                                             "bench harness)" if use_rank_api else None),
+                         note=("the engine's halo exchange: RCCL bound at first use -- LBM_RCCL_LIB, else the librccl "
+                               "already in the process (torch's here), else /opt/rocm/lib; nranks = ncclCommCount of "
+                               "the engine's communicator" if (r.get("rccl") or {}).get("loaded") else
+                               "single slab: no communicator, RCCL not loaded by the engine")),
         }
         if check:
             line["multi_gpu_check"] = dict(check)
@@ -365,8 +452,11 @@ def main():
         rel = float(np.max(np.abs(av.astype(np.float64) - ref_av) / np.abs(ref_av)))
         t = torch.tensor([0.0 if same else 1.0, rel], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        seen = main_result.get("rccl") or eng.rccl_info()
         check.update({"fields_bitwise_equal_to_single_gpu_run": bool(t[0] == 0.0),
-                      "av_vels_max_rel_diff": float(t[1]), "ranks_checked": world, "steps": total})
+                      "av_vels_max_rel_diff": float(t[1]), "ranks_checked": world, "steps": total,
+                      "rccl": {k: seen.get(k) for k in ("version_string", "nranks", "nranks_min_over_ranks",
+                                                         "nranks_max_over_ranks", "library")}})
 
     watchdog = threading.Timer(extras_timeout, extras_watchdog)
     watchdog.daemon = True
@@ -436,8 +526,17 @@ def main():
         finite = bool(np.isfinite(av).all())
         info = eng.info()
         if headline:
+            rc_info = eng.rccl_info()
+            if use_rank_api:
+                # every rank's view of the ring: the record must show that RCCL saw `world` ranks on all of them
+                t = torch.tensor([float(rc_info["nranks"]), -float(rc_info["nranks"]), float(rc_info["version"])],
+                                 dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                rc_info["nranks_min_over_ranks"] = int(-t[1])
+                rc_info["nranks_max_over_ranks"] = int(t[0])
+                rc_info["version_max_over_ranks"] = int(t[2])
             main_result.update(elapsed=elapsed, kernel_ms=kernel_ms, info=info, finite=finite, workload=workload,
-                               repeats=[e for e, _ in runs], prewarm_steps=prewarm_steps)
+                               repeats=[e for e, _ in runs], prewarm_steps=prewarm_steps, rccl=rc_info)
             verify_wanted[0] = verify
             watchdog.start()
         if verify:

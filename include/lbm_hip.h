@@ -78,8 +78,9 @@ typedef struct {
   int    math_mode;      /* LBM_MATH_EXACT or LBM_MATH_FAST */
   int    world_rank;     /* rank of this context in a multi-process run (0 otherwise) */
   int    world_size;     /* number of processes sharing the grid (1 otherwise) */
-  int    steps_per_launch; /* timesteps one launch of the main kernel advances: 2 or 3 for the
-                              stream kernels (large grids), 3-4 for the LDS-tile kernel, else 1 */
+  int    steps_per_launch; /* timesteps one launch of the main kernel advances: 2-4 for the stream kernels
+                              (three from 300 Ki cells, four from 3.5 Mi cells per slab), 3-4 for the LDS-tile
+                              kernel (small single slabs), else 1 */
   int    halo_mode;      /* LBM_HALO_SYNC or LBM_HALO_STALE (meaningful with several slabs / ranks) */
   int    band_rows;      /* launch geometry of the multi-step stream kernel: rows one wave sweeps ... */
   int    lane_cells;     /* ... and cells per lane (4 or 2); 0 / 0 when another kernel is the main one */
@@ -153,6 +154,28 @@ lbm_ctx* lbm_create(const lbm_params* params, const int* obstacles, const float*
  */
 #define LBM_RCCL_ID_BYTES 128
 int      lbm_rccl_unique_id(void* id_out);
+
+/*
+ * Which RCCL serves the halo exchange, and what it says about the ring -- the question "did RCCL see N ranks, and
+ * which RCCL" of a multi-GPU run, answered from the run's own record (the reference prints "Process %d of %d started",
+ * MPI/d2q9-bgk.c:151, from MPI_Comm_rank / MPI_Comm_size, MPI_Waitall/d2q9-bgk.c:143-147).
+ * RCCL is bound at first use, not at link time, in this order: the file named by LBM_RCCL_LIB; a librccl.so.1 the
+ * process has already mapped (a host that imported PyTorch carries PyTorch's bundled RCCL next to its bundled HIP
+ * runtime -- a communicator has to come from the RCCL built for the HIP runtime in the process); ROCm's own
+ * /opt/rocm/lib/librccl.so.1.  A single-GPU run never loads it.
+ * ctx == NULL: binds the library and reports `loaded`, `version`, `library`.  With a context: its communicators
+ * (n_comms: one per slab in the one-process form, one in the one-process-per-GPU form, none for a single slab or the
+ * device-copy / hosted transports) and nranks / rank as ncclCommCount / ncclCommUserRank of the first one report them.
+ */
+typedef struct {
+  int  loaded;        /* 1: a librccl is bound to this engine */
+  int  version;       /* ncclGetVersion(), e.g. 22707 = 2.27.7 */
+  int  n_comms;       /* communicators the context holds */
+  int  nranks;        /* ranks in the ring as RCCL counts them (ncclCommCount); 0 without a communicator */
+  int  rank;          /* this context's rank in it (ncclCommUserRank) */
+  char library[512];  /* file the RCCL entry points were bound from */
+} lbm_rccl_status;
+int      lbm_rccl_info(const lbm_ctx* ctx, lbm_rccl_status* out);
 lbm_ctx* lbm_create_rank(const lbm_params* params, const int* obstacles, const float* cells_aos,
                          int rank, int world_size, const void* unique_id, int device,
                          int math_mode);
@@ -196,7 +219,8 @@ lbm_ctx* lbm_create_rank_tiled(const lbm_params* params, const int* tile, int ti
  *   allreduce_sum(user, values, n): in-place sum of n doubles over all ranks; every rank receives it.  Return 0.
  * The callbacks block the host, so this transport does not hide the exchange behind the interior rows; it exists for
  * MPI-launched hosts and to run the rank decomposition with several ranks on ONE device (tests).  obstacles /
- * cells_aos: the global arrays, as lbm_create_rank.  Every rank must issue the same sequence of calls.
+ * cells_aos: the global arrays, as lbm_create_rank (the _rows / _tiled forms below take only a rank's share).
+ * Every rank must issue the same sequence of calls.
  */
 typedef struct {
   int (*exchange)(void* user, int n_ops, const lbm_halo_op* ops, float* const* buffers, size_t floats_per_message);
@@ -206,6 +230,18 @@ typedef struct {
 lbm_ctx* lbm_create_rank_hosted(const lbm_params* params, const int* obstacles, const float* cells_aos,
                                 int rank, int world_size, const lbm_host_comm* comm, int device,
                                 int math_mode);
+/*
+ * The same without the global arrays on every rank -- what the reference's MPI programs do: rank 0 parses the
+ * obstacle file and sends every rank its rows (MPI_Waitall/d2q9-bgk.c:816-842).  Arguments as lbm_create_rank_rows
+ * (this rank's rows with LBM_MASK_HALO_ROWS periodic neighbour rows on each side; this rank's cells or NULL) and
+ * lbm_create_rank_tiled (a small tile repeated over the grid, expanded on the device).
+ */
+lbm_ctx* lbm_create_rank_hosted_rows(const lbm_params* params, const int* obstacle_rows, const float* cells_rows_aos,
+                                     int rank, int world_size, const lbm_host_comm* comm, int device,
+                                     int math_mode);
+lbm_ctx* lbm_create_rank_hosted_tiled(const lbm_params* params, const int* tile, int tile_nx, int tile_ny,
+                                      int rank, int world_size, const lbm_host_comm* comm, int device,
+                                      int math_mode);
 
 void     lbm_destroy(lbm_ctx* ctx);
 int      lbm_get_info(const lbm_ctx* ctx, lbm_info* out);

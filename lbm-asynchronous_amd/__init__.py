@@ -39,8 +39,9 @@ _HALO = {"sync": HALO_SYNC, "stale": HALO_STALE, HALO_SYNC: HALO_SYNC, HALO_STAL
 # every symbol include/lbm_hip.h declares (tests check the .so exports them all)
 ABI_SYMBOLS = (
     "lbm_set_error_mode", "lbm_last_error", "lbm_version", "lbm_device_count",
-    "lbm_partition_rows", "lbm_halo_plan", "lbm_plan_halo_depth", "lbm_create", "lbm_rccl_unique_id", "lbm_create_rank", "lbm_create_rank_rows",
-    "lbm_create_tiled", "lbm_create_rank_tiled", "lbm_create_rank_hosted", "lbm_destroy",
+    "lbm_partition_rows", "lbm_halo_plan", "lbm_plan_halo_depth", "lbm_create", "lbm_rccl_unique_id", "lbm_rccl_info", "lbm_create_rank", "lbm_create_rank_rows",
+    "lbm_create_tiled", "lbm_create_rank_tiled", "lbm_create_rank_hosted", "lbm_create_rank_hosted_rows",
+    "lbm_create_rank_hosted_tiled", "lbm_destroy",
     "lbm_get_info", "lbm_set_halo_mode", "lbm_run", "lbm_sync", "lbm_run_timed", "lbm_read_av_vels", "lbm_read_cells",
     "lbm_read_final_state", "lbm_av_velocity", "lbm_total_density", "lbm_calc_reynolds",
 )
@@ -63,6 +64,11 @@ class _CInfo(ctypes.Structure):
                 ("world_size", ctypes.c_int), ("steps_per_launch", ctypes.c_int),
                 ("halo_mode", ctypes.c_int), ("band_rows", ctypes.c_int), ("lane_cells", ctypes.c_int),
                 ("nontemporal", ctypes.c_int), ("graph_steps", ctypes.c_int)]
+
+
+class _CRcclStatus(ctypes.Structure):
+    _fields_ = [("loaded", ctypes.c_int), ("version", ctypes.c_int), ("n_comms", ctypes.c_int),
+                ("nranks", ctypes.c_int), ("rank", ctypes.c_int), ("library", ctypes.c_char * 512)]
 
 
 class _CHaloOp(ctypes.Structure):
@@ -128,6 +134,7 @@ def load_library() -> ctypes.CDLL:
     lib.lbm_plan_halo_depth.argtypes = [ctypes.POINTER(_CParams), I, I]; lib.lbm_plan_halo_depth.restype = I
     lib.lbm_create.argtypes = [ctypes.POINTER(_CParams), P, P, I, I]; lib.lbm_create.restype = P
     lib.lbm_rccl_unique_id.argtypes = [P]; lib.lbm_rccl_unique_id.restype = I
+    lib.lbm_rccl_info.argtypes = [P, ctypes.POINTER(_CRcclStatus)]; lib.lbm_rccl_info.restype = I
     lib.lbm_create_rank.argtypes = [ctypes.POINTER(_CParams), P, P, I, I, P, I, I]
     lib.lbm_create_rank.restype = P
     lib.lbm_create_rank_rows.argtypes = [ctypes.POINTER(_CParams), P, P, I, I, P, I, I]
@@ -137,6 +144,10 @@ def load_library() -> ctypes.CDLL:
     lib.lbm_create_rank_tiled.restype = P
     lib.lbm_create_rank_hosted.argtypes = [ctypes.POINTER(_CParams), P, P, I, I, ctypes.POINTER(_CHostComm), I, I]
     lib.lbm_create_rank_hosted.restype = P
+    lib.lbm_create_rank_hosted_rows.argtypes = [ctypes.POINTER(_CParams), P, P, I, I, ctypes.POINTER(_CHostComm), I, I]
+    lib.lbm_create_rank_hosted_rows.restype = P
+    lib.lbm_create_rank_hosted_tiled.argtypes = [ctypes.POINTER(_CParams), P, I, I, I, I, ctypes.POINTER(_CHostComm), I, I]
+    lib.lbm_create_rank_hosted_tiled.restype = P
     lib.lbm_destroy.argtypes = [P]; lib.lbm_destroy.restype = None
     lib.lbm_get_info.argtypes = [P, ctypes.POINTER(_CInfo)]; lib.lbm_get_info.restype = I
     lib.lbm_set_halo_mode.argtypes = [P, I]; lib.lbm_set_halo_mode.restype = I
@@ -192,6 +203,21 @@ def plan_halo_depth(params: "Params", parts: int, math: str | int = "exact") -> 
     return int(d)
 
 
+def _rccl_status(lib, handle) -> dict:
+    st = _CRcclStatus()
+    _check(lib, lib.lbm_rccl_info(handle, ctypes.byref(st)))
+    v = st.version
+    return {"loaded": bool(st.loaded), "version": v,
+            "version_string": f"{v // 10000}.{v // 100 % 100}.{v % 100}" if v else None,
+            "n_comms": st.n_comms, "nranks": st.nranks, "rank": st.rank,
+            "library": st.library.decode() or None}
+
+
+def rccl_info() -> dict:
+    """Bind RCCL as the first multi-GPU create would and report which library and version (lbm_rccl_info(NULL))."""
+    return _rccl_status(load_library(), None)
+
+
 def rccl_unique_id() -> bytes:
     lib = load_library()
     buf = ctypes.create_string_buffer(RCCL_ID_BYTES)
@@ -244,11 +270,21 @@ class Engine:
         cp = params._c()
         idbuf = ctypes.create_string_buffer(unique_id, RCCL_ID_BYTES) if unique_id else None
         if host_comm is not None:
-            if rank is None or tiled or local_rows:
-                raise LbmError("host_comm needs the rank form with the global obstacle map")
+            if rank is None:
+                raise LbmError("host_comm needs the rank form")
             self._host_comm = self._wrap_host_comm(*host_comm)
-            h = self.lib.lbm_create_rank_hosted(ctypes.byref(cp), obstacles.ctypes.data, cptr, rank, world_size,
-                                                ctypes.byref(self._host_comm), device, _MATH[math])
+            if tiled:
+                if cells is not None:
+                    raise LbmError("lbm_create_rank_hosted_tiled starts from the uniform equilibrium")
+                h = self.lib.lbm_create_rank_hosted_tiled(ctypes.byref(cp), obstacles.ctypes.data, obstacles.shape[1],
+                                                          obstacles.shape[0], rank, world_size,
+                                                          ctypes.byref(self._host_comm), device, _MATH[math])
+            elif local_rows:
+                h = self.lib.lbm_create_rank_hosted_rows(ctypes.byref(cp), obstacles.ctypes.data, cptr, rank, world_size,
+                                                         ctypes.byref(self._host_comm), device, _MATH[math])
+            else:
+                h = self.lib.lbm_create_rank_hosted(ctypes.byref(cp), obstacles.ctypes.data, cptr, rank, world_size,
+                                                    ctypes.byref(self._host_comm), device, _MATH[math])
         elif rank is None:
             if tiled:
                 h = self.lib.lbm_create_tiled(ctypes.byref(cp), obstacles.ctypes.data, obstacles.shape[1],
@@ -319,6 +355,10 @@ class Engine:
         ci = _CInfo()
         _check(self.lib, self.lib.lbm_get_info(self.handle, ctypes.byref(ci)))
         return {name: getattr(ci, name) for name, _ in _CInfo._fields_}
+
+    def rccl_info(self) -> dict:
+        """Which RCCL this context's communicators come from and what they say about the ring (lbm_rccl_info)."""
+        return _rccl_status(self.lib, self.handle)
 
     def set_halo_mode(self, mode) -> None:
         """'sync' (halo rows of the same timestep, the MPI_Waitall pattern) or 'stale' (one pass

@@ -11,6 +11,8 @@
 #include <hip/hip_ext.h>
 #include <rccl/rccl.h>
 
+#include <dlfcn.h>
+
 #include <atomic>
 #include <condition_variable>
 #include <cstdarg>
@@ -61,7 +63,7 @@ void raise_error(int line, const char* fmt, ...) {
 #define NCCL_TRY(ret, expr)                                                               \
   do {                                                                                    \
     ncclResult_t r_ = (expr);                                                             \
-    if (r_ != ncclSuccess) LBM_FAIL(ret, "RCCL error: %s (%s)", ncclGetErrorString(r_), #expr); \
+    if (r_ != ncclSuccess) LBM_FAIL(ret, "RCCL error: %s (%s)", g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?", #expr); \
   } while (0)
 
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
@@ -71,6 +73,83 @@ int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
 }
+
+
+// ---- RCCL, bound at first use -----------------------------------------------------------------------------------
+// The library is NOT a link-time dependency: a single-GPU run never loads it, and WHICH librccl serves a multi-GPU
+// run is a decision taken here, not an accident of load order:
+//   1. LBM_RCCL_LIB=<path>: that file (RTLD_LOCAL | RTLD_DEEPBIND);
+//   2. a librccl.so.1 the process has already mapped -- a host that imported PyTorch first carries torch's bundled
+//      RCCL together with torch's bundled HIP runtime (both resolve by soname before anything of this engine loads),
+//      and a communicator must come from the RCCL built for the HIP runtime it runs on;
+//   3. ROCm's own, /opt/rocm/lib/librccl.so.1 (then the bare soname): the C host program and torch-free hosts.
+// lbm_rccl_info() reports which one it was, its version and what the communicator says about the ring.
+struct RcclApi {
+  void* handle = nullptr;
+  char path[512] = "";
+  ncclResult_t (*GetVersion)(int*) = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+std::once_flag g_rccl_once;
+char g_rccl_error[768] = "";
+
+void rccl_bind() {
+  RcclApi& r = g_rccl;
+  const char* forced = getenv("LBM_RCCL_LIB");
+  if (forced && *forced) {
+    r.handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
+    if (!r.handle) { snprintf(g_rccl_error, sizeof(g_rccl_error), "LBM_RCCL_LIB=%s: %s", forced, dlerror()); return; }
+  } else {
+    r.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);  // already in the process (e.g. PyTorch's)
+    if (!r.handle) r.handle = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!r.handle) r.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!r.handle) { snprintf(g_rccl_error, sizeof(g_rccl_error), "librccl.so.1 not found: %s", dlerror()); return; }
+  }
+  bool ok = true;
+  auto sym = [&](const char* name) -> void* {
+    void* p = dlsym(r.handle, name);
+    if (!p) { ok = false; snprintf(g_rccl_error, sizeof(g_rccl_error), "librccl lacks %s", name); }
+    return p;
+  };
+#define LBM_RCCL_SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(sym(name))
+  LBM_RCCL_SYM(GetVersion, "ncclGetVersion");        LBM_RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
+  LBM_RCCL_SYM(CommInitRank, "ncclCommInitRank");    LBM_RCCL_SYM(CommInitAll, "ncclCommInitAll");
+  LBM_RCCL_SYM(CommDestroy, "ncclCommDestroy");      LBM_RCCL_SYM(CommCount, "ncclCommCount");
+  LBM_RCCL_SYM(CommUserRank, "ncclCommUserRank");    LBM_RCCL_SYM(GroupStart, "ncclGroupStart");
+  LBM_RCCL_SYM(GroupEnd, "ncclGroupEnd");            LBM_RCCL_SYM(Send, "ncclSend");
+  LBM_RCCL_SYM(Recv, "ncclRecv");                    LBM_RCCL_SYM(AllReduce, "ncclAllReduce");
+  LBM_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef LBM_RCCL_SYM
+  if (!ok) { r.handle = nullptr; return; }
+  Dl_info di;
+  if (dladdr(reinterpret_cast<void*>(r.GetVersion), &di) && di.dli_fname) {
+    char real[512];
+    const char* shown = realpath(di.dli_fname, real) ? real : di.dli_fname;
+    strncpy(r.path, shown, sizeof(r.path) - 1);
+  }
+}
+
+// the bound RCCL, or nullptr with the reason in g_rccl_error
+RcclApi* rccl() {
+  std::call_once(g_rccl_once, rccl_bind);
+  return g_rccl.handle ? &g_rccl : nullptr;
+}
+
+#define RCCL_OR_FAIL(ret)                                                       \
+  RcclApi* rc_api_ = rccl();                                                    \
+  if (!rc_api_) LBM_FAIL(ret, "RCCL is not available: %s", g_rccl_error)
 
 struct Slab {
   int device = 0;
@@ -204,6 +283,30 @@ struct SlabTeam {
 
 }  // namespace
 
+// A hipGraph chunk is BUILT, not captured: the issue code below runs against these virtual streams and events, which
+// keep exactly the bookkeeping stream capture would (a stream's pending dependencies, an event's snapshot of them) and
+// turn every launch / copy into an explicit node with explicit dependencies.  Multi-stream capture cannot be used:
+// hip::Stream::EndCapture() of ROCm 7.2 recurses without end once three or more side streams have waited on each
+// other's events (profiles/r03_graph_capture_defect.md, tools/capture_ring_repro.hip).
+struct GraphBuilder {
+  hipGraph_t graph = nullptr;
+  struct VStream { hipStream_t key; std::vector<hipGraphNode_t> last; };
+  struct VEvent { hipEvent_t key; std::vector<hipGraphNode_t> nodes; };
+  std::vector<VStream> streams;
+  std::vector<VEvent> events;
+  std::vector<hipGraphNode_t>& last_of(hipStream_t st) {
+    for (auto& v : streams) if (v.key == st) return v.last;
+    streams.push_back({st, {}});
+    return streams.back().last;
+  }
+  std::vector<hipGraphNode_t>* snapshot_of(hipEvent_t ev, bool create) {
+    for (auto& v : events) if (v.key == ev) return &v.nodes;
+    if (!create) return nullptr;
+    events.push_back({ev, {}});
+    return &events.back().nodes;
+  }
+};
+
 struct lbm_ctx {
   lbm_params p;
   int pitch = 0;
@@ -243,6 +346,7 @@ struct lbm_ctx {
   int lane_cells = 4;               // cells per lane in step2_stream (4 or 2; LBM_LANE_CELLS)
   SlabTeam* team = nullptr;         // one issuing thread per slab (one-process multi-GPU), or null
   int use_graph = 0;                // replay chunks of an even number of passes + their reduce as one hipGraph each
+  GraphBuilder* builder = nullptr;  // non-null while a chunk is being built: launches become graph nodes
   int tile_steps = 0;               // > 0: single slab advanced by the LDS-tile kernel, this many steps per launch
   int tile_shape = 0;               // index into kTileShapes
 };
@@ -254,6 +358,54 @@ int for_slabs(lbm_ctx* c, const std::function<int(int)>& body) {
   if (c->team) return c->team->run(c->n_slabs, body);
   for (int s = 0; s < c->n_slabs; s++)
     if (body(s) != LBM_SUCCESS) return LBM_FAILURE;
+  return LBM_SUCCESS;
+}
+
+// ---- stream operations that become graph nodes / edges while a chunk is being built ---------------------------
+int q_wait(lbm_ctx* c, hipStream_t st, hipEvent_t ev) {
+  if (!c->builder) { HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(st, ev, 0)); return LBM_SUCCESS; }
+  const std::vector<hipGraphNode_t>* snap = c->builder->snapshot_of(ev, false);
+  if (!snap) return LBM_SUCCESS;  // never recorded inside this chunk: "ready when the chunk starts"
+  std::vector<hipGraphNode_t>& last = c->builder->last_of(st);
+  for (hipGraphNode_t n : *snap) {
+    bool have = false;
+    for (hipGraphNode_t m : last) have = have || (m == n);
+    if (!have) last.push_back(n);
+  }
+  return LBM_SUCCESS;
+}
+int q_record(lbm_ctx* c, hipEvent_t ev, hipStream_t st) {
+  if (!c->builder) { HIP_TRY(LBM_FAILURE, hipEventRecord(ev, st)); return LBM_SUCCESS; }
+  const std::vector<hipGraphNode_t> now = c->builder->last_of(st);  // copy: snapshot_of may grow the event table
+  *c->builder->snapshot_of(ev, true) = now;
+  return LBM_SUCCESS;
+}
+// launch fn(args...) on st; `done` (optional, stream mode): event bound to the kernel's own completion signal
+int q_kernel(lbm_ctx* c, hipStream_t st, const void* fn, dim3 grid, dim3 block, void** args, hipEvent_t done = nullptr) {
+  if (c->builder) {
+    hipKernelNodeParams kp;
+    memset(&kp, 0, sizeof(kp));
+    kp.func = const_cast<void*>(fn);
+    kp.gridDim = grid;
+    kp.blockDim = block;
+    kp.kernelParams = args;
+    std::vector<hipGraphNode_t>& last = c->builder->last_of(st);
+    hipGraphNode_t node = nullptr;
+    HIP_TRY(LBM_FAILURE, hipGraphAddKernelNode(&node, c->builder->graph, last.data(), last.size(), &kp));
+    last.assign(1, node);
+    if (done) *c->builder->snapshot_of(done, true) = last;
+    return LBM_SUCCESS;
+  }
+  if (done) HIP_TRY(LBM_FAILURE, hipExtLaunchKernel(fn, grid, block, args, 0, st, nullptr, done, 0));
+  else HIP_TRY(LBM_FAILURE, hipLaunchKernel(fn, grid, block, args, 0, st));
+  return LBM_SUCCESS;
+}
+int q_copy(lbm_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t st) {
+  if (!c->builder) { HIP_TRY(LBM_FAILURE, hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, st)); return LBM_SUCCESS; }
+  std::vector<hipGraphNode_t>& last = c->builder->last_of(st);
+  hipGraphNode_t node = nullptr;
+  HIP_TRY(LBM_FAILURE, hipGraphAddMemcpyNode1D(&node, c->builder->graph, last.data(), last.size(), dst, src, bytes, hipMemcpyDeviceToDevice));
+  last.assign(1, node);
   return LBM_SUCCESS;
 }
 
@@ -296,17 +448,14 @@ int launch_step(lbm_ctx* c, int s, hipStream_t stream, int row_first, int row_st
         {{lbm::step_vec4<1, 0, false>, lbm::step_vec4<1, 0, true>},
          {lbm::step_vec4<1, 1, false>, lbm::step_vec4<1, 1, true>},
          {lbm::step_vec4<1, 2, false>, lbm::step_vec4<1, 2, true>}}};
-    if (done) hipExtLaunchKernelGGL(table[exact ? 0 : 1][c->neigh][c->nts], dim3(blocks), dim3(lbm::kBlock), 0, stream,
-                                    nullptr, done, 0, a);
-    else hipLaunchKernelGGL(table[exact ? 0 : 1][c->neigh][c->nts], dim3(blocks), dim3(lbm::kBlock), 0, stream, a);
+    void* args[] = {&a};
+    return q_kernel(c, stream, reinterpret_cast<const void*>(table[exact ? 0 : 1][c->neigh][c->nts]), dim3(blocks), dim3(lbm::kBlock), args, done);
   } else {
     const int blocks = ceil_div((long)c->p.nx * n_rows, lbm::kBlock);
     const auto fn = exact ? lbm::step_scalar<true> : lbm::step_scalar<false>;
-    if (done) hipExtLaunchKernelGGL(fn, dim3(blocks), dim3(lbm::kBlock), 0, stream, nullptr, done, 0, a);
-    else hipLaunchKernelGGL(fn, dim3(blocks), dim3(lbm::kBlock), 0, stream, a);
+    void* args[] = {&a};
+    return q_kernel(c, stream, reinterpret_cast<const void*>(fn), dim3(blocks), dim3(lbm::kBlock), args, done);
   }
-  HIP_TRY(LBM_FAILURE, hipGetLastError());
-  return LBM_SUCCESS;
 }
 
 // two timesteps in one pass over the rows [row_first, row_end) of slab s, cut into band_count bands of
@@ -347,10 +496,8 @@ int launch_step2(lbm_ctx* c, int s, hipStream_t stream, int row_first, int row_e
       {{lbm::step2_stream<1, false, 4>, lbm::step2_stream<1, false, 2>},
        {lbm::step2_stream<1, true, 4>, lbm::step2_stream<1, true, 2>}}};
   const fn kernel = table[c->math_mode == LBM_MATH_EXACT ? 0 : 1][c->nts][c->lane_cells == 2 ? 1 : 0];
-  if (done) hipExtLaunchKernelGGL(kernel, dim3(waves), dim3(64), 0, stream, nullptr, done, 0, a);
-  else hipLaunchKernelGGL(kernel, dim3(waves), dim3(64), 0, stream, a);
-  HIP_TRY(LBM_FAILURE, hipGetLastError());
-  return LBM_SUCCESS;
+  void* args[] = {&a};
+  return q_kernel(c, stream, reinterpret_cast<const void*>(kernel), dim3(waves), dim3(64), args, done);
 }
 
 // k (2..3) timesteps in one pass over the rows [row_first, row_end) of slab s (4 cells per lane), cut into band_count
@@ -418,10 +565,8 @@ int launch_stepk(lbm_ctx* c, int s, hipStream_t stream, int k, int row_first, in
   const fn kernel = (packed && c->lane_cells == 2) ? table_pk1[c->nts][k - 2][c->prefetch ? 1 : 0][lds_windows ? 1 : 0]
                     : packed ? table_pk[c->nts][k - 2][c->prefetch ? 1 : 0][lds_windows]
                            : table[c->math_mode == LBM_MATH_EXACT ? 0 : 1][c->nts][k - 2][c->prefetch ? 1 : 0];
-  if (done) hipExtLaunchKernelGGL(kernel, dim3(waves), dim3(64), 0, stream, nullptr, done, 0, a);
-  else hipLaunchKernelGGL(kernel, dim3(waves), dim3(64), 0, stream, a);
-  HIP_TRY(LBM_FAILURE, hipGetLastError());
-  return LBM_SUCCESS;
+  void* args[] = {&a};
+  return q_kernel(c, stream, reinterpret_cast<const void*>(kernel), dim3(waves), dim3(64), args, done);
 }
 
 // the stream kernel for a k-step pass: the 2-cells-per-lane form exists for k = 2 only (step2_stream)
@@ -464,9 +609,9 @@ int launch_tile(lbm_ctx* c, hipStream_t stream, int n_steps, bool accel_after) {
   a.slot_stride = c->part_stride;
   const TileShape& t = kTileShapes[c->tile_shape];
   a.tiles_x = ceil_div(c->p.nx, t.tw);
-  hipLaunchKernelGGL(c->math_mode == LBM_MATH_EXACT ? t.exact : t.fast, dim3(tile_count(c)), dim3(t.threads), 0, stream, a);
-  HIP_TRY(LBM_FAILURE, hipGetLastError());
-  return LBM_SUCCESS;
+  void* args[] = {&a};
+  return q_kernel(c, stream, reinterpret_cast<const void*>(c->math_mode == LBM_MATH_EXACT ? t.exact : t.fast), dim3(tile_count(c)),
+                  dim3(t.threads), args);
 }
 
 int blocks_for_rows(const lbm_ctx* c, int n_rows) {
@@ -503,34 +648,64 @@ int exchange_halos(lbm_ctx* c, int depth, int src, int dst, int slot) {
       }
     }
     // one thread driving several communicators must group them; with one thread per slab each
-    // thread groups its own four operations
-    if (!c->team) NCCL_TRY(LBM_FAILURE, ncclGroupStart());
-    const int rc = for_slabs(c, [&](int s) -> int {
+    // thread groups its own four operations.  A group once opened is closed on every path: an error inside it must
+    // not leave the communicator in group mode.
+    RCCL_OR_FAIL(LBM_FAILURE);
+    const RcclApi& nc = *rc_api_;
+    // while a chunk is being built: the group is captured on the (single) comm stream alone -- a capture with one
+    // user stream, its origin -- and enters the chunk as a child-graph node behind the comm stream's dependencies
+    const bool building = (c->builder != nullptr);
+    if (building) {
+      if (c->n_slabs != 1) LBM_FAIL(LBM_FAILURE, "hipGraph chunk: the RCCL transport is built for one communicator per process");
+      HIP_TRY(LBM_FAILURE, hipStreamBeginCapture(c->slab[0].comm, hipStreamCaptureModeRelaxed));
+    }
+    if (!c->team) NCCL_TRY(LBM_FAILURE, nc.GroupStart());
+    int rc = for_slabs(c, [&](int s) -> int {
       Slab& sl = c->slab[s];
       float* from = sl.lat[src];
       float* to = sl.lat[dst];
       int me, parts;
       if (c->ranked) { me = c->rank; parts = c->world; } else { me = s; parts = c->n_slabs; }
-      if (c->team) {
-        HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
-        NCCL_TRY(LBM_FAILURE, ncclGroupStart());
-      }
       // the four operations in the posting order of lbm_halo_plan (the order matters when north == south, 2 parts:
       // the first send pairs with the peer's first receive)
       lbm_halo_op ops[4];
       if (lbm_halo_plan(sl.rows, parts, me, depth, ops) != LBM_SUCCESS) return LBM_FAILURE;
-      for (int i = 0; i < 4; i++) {
-        if (ops[i].is_send)
-          NCCL_TRY(LBM_FAILURE, ncclSend(from + (long)ops[i].row_first * c->row_pitch, (size_t)ops[i].row_count * c->row_pitch,
-                                         ncclFloat, ops[i].peer, sl.nccl, sl.comm));
-        else
-          NCCL_TRY(LBM_FAILURE, ncclRecv(to + (long)ops[i].row_first * c->row_pitch, (size_t)ops[i].row_count * c->row_pitch,
-                                         ncclFloat, ops[i].peer, sl.nccl, sl.comm));
+      if (c->team) {
+        HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+        NCCL_TRY(LBM_FAILURE, nc.GroupStart());
       }
-      if (c->team) NCCL_TRY(LBM_FAILURE, ncclGroupEnd());
+      ncclResult_t res = ncclSuccess;
+      for (int i = 0; i < 4 && res == ncclSuccess; i++) {
+        float* base = ops[i].is_send ? from : to;
+        float* ptr = base + (long)ops[i].row_first * c->row_pitch;
+        const size_t count = (size_t)ops[i].row_count * c->row_pitch;
+        res = ops[i].is_send ? nc.Send(ptr, count, ncclFloat, ops[i].peer, sl.nccl, sl.comm)
+                             : nc.Recv(ptr, count, ncclFloat, ops[i].peer, sl.nccl, sl.comm);
+      }
+      if (c->team) {
+        const ncclResult_t end = nc.GroupEnd();
+        if (res == ncclSuccess) res = end;
+      }
+      if (res != ncclSuccess) LBM_FAIL(LBM_FAILURE, "RCCL error in the halo exchange: %s", nc.GetErrorString(res));
       return LBM_SUCCESS;
     });
-    if (!c->team) NCCL_TRY(LBM_FAILURE, ncclGroupEnd());
+    if (!c->team) {
+      const ncclResult_t end = nc.GroupEnd();
+      if (rc == LBM_SUCCESS && end != ncclSuccess) { raise_error(__LINE__, "RCCL error: %s (ncclGroupEnd)", nc.GetErrorString(end)); rc = LBM_FAILURE; }
+    }
+    if (building) {
+      hipGraph_t child = nullptr;
+      const hipError_t ended = hipStreamEndCapture(c->slab[0].comm, &child);
+      if (rc == LBM_SUCCESS && ended != hipSuccess) { raise_error(__LINE__, "HIP error: %s (capture of the RCCL group)", hipGetErrorString(ended)); rc = LBM_FAILURE; }
+      if (rc == LBM_SUCCESS) {
+        std::vector<hipGraphNode_t>& last = c->builder->last_of(c->slab[0].comm);
+        hipGraphNode_t node = nullptr;
+        const hipError_t added = hipGraphAddChildGraphNode(&node, c->builder->graph, last.data(), last.size(), child);
+        if (added != hipSuccess) { raise_error(__LINE__, "HIP error: %s (hipGraphAddChildGraphNode)", hipGetErrorString(added)); rc = LBM_FAILURE; }
+        else last.assign(1, node);
+      }
+      if (child) (void)hipGraphDestroy(child);  // the node holds its own copy
+    }
     if (rc != LBM_SUCCESS) return rc;
     if (stale) {
       for (int s = 0; s < c->n_slabs; s++) {
@@ -575,15 +750,12 @@ int exchange_halos(lbm_ctx* c, int depth, int src, int dst, int slot) {
       Slab& sn = c->slab[north];
       Slab& ss = c->slab[south];
       HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
-      if (stale) HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sl.ev_step, 0));
-      HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, stale ? sn.ev_step : sn.ev_boundary, 0));
-      HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, stale ? ss.ev_step : ss.ev_boundary, 0));
-      HIP_TRY(LBM_FAILURE, hipMemcpyAsync(sn.lat[dst] - n, from + (long)(sl.rows - depth) * c->row_pitch,
-                                          n * sizeof(float), hipMemcpyDefault, sl.comm));
-      HIP_TRY(LBM_FAILURE, hipMemcpyAsync(ss.lat[dst] + (long)ss.rows * c->row_pitch, from, n * sizeof(float),
-                                          hipMemcpyDefault, sl.comm));
-      HIP_TRY(LBM_FAILURE, hipEventRecord(stale ? sl.ev_x[slot] : sl.ev_halo, sl.comm));
-      return LBM_SUCCESS;
+      if (stale && q_wait(c, sl.comm, sl.ev_step) != LBM_SUCCESS) return LBM_FAILURE;
+      if (q_wait(c, sl.comm, stale ? sn.ev_step : sn.ev_boundary) != LBM_SUCCESS) return LBM_FAILURE;
+      if (q_wait(c, sl.comm, stale ? ss.ev_step : ss.ev_boundary) != LBM_SUCCESS) return LBM_FAILURE;
+      if (q_copy(c, sn.lat[dst] - n, from + (long)(sl.rows - depth) * c->row_pitch, n * sizeof(float), sl.comm) != LBM_SUCCESS) return LBM_FAILURE;
+      if (q_copy(c, ss.lat[dst] + (long)ss.rows * c->row_pitch, from, n * sizeof(float), sl.comm) != LBM_SUCCESS) return LBM_FAILURE;
+      return q_record(c, stale ? sl.ev_x[slot] : sl.ev_halo, sl.comm);
     });
   }
   return LBM_SUCCESS;
@@ -683,7 +855,7 @@ int issue_pass(lbm_ctx* c, int m, int tile, int k, bool accel_after, bool bound_
   if (for_slabs(c, [&](int s) -> int {
         Slab& sl = c->slab[s];
         HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
-        if (halo && m > 0) HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, sl.ev_boundary, 0));  // B(m-1)
+        if (halo && m > 0 && q_wait(c, sl.compute, sl.ev_boundary) != LBM_SUCCESS) return LBM_FAILURE;  // B(m-1)
         hipEvent_t done = (halo && bound_events) ? sl.ev_interior[m & 1] : nullptr;  // I(m) done
         if (tile) {
           if (launch_tile(c, sl.compute, tile, accel_after) != LBM_SUCCESS) return LBM_FAILURE;
@@ -697,7 +869,7 @@ int issue_pass(lbm_ctx* c, int m, int tile, int k, bool accel_after, bool bound_
         } else {
           if (launch_step(c, s, sl.compute, 1, 1, sl.rows - 2, 0, accel_after, done) != LBM_SUCCESS) return LBM_FAILURE;
         }
-        if (halo && !done) HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_interior[m & 1], sl.compute));
+        if (halo && !done) return q_record(c, sl.ev_interior[m & 1], sl.compute);
         return LBM_SUCCESS;
       }) != LBM_SUCCESS)
     return LBM_FAILURE;
@@ -706,11 +878,11 @@ int issue_pass(lbm_ctx* c, int m, int tile, int k, bool accel_after, bool bound_
       for_slabs(c, [&](int s) -> int {
         Slab& sl = c->slab[s];
         HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
-        HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sl.ev_interior[(m + 1) & 1], 0));  // I(m-1)
+        if (q_wait(c, sl.comm, sl.ev_interior[(m + 1) & 1]) != LBM_SUCCESS) return LBM_FAILURE;  // I(m-1)
         if (c->halo == HALO_MEMCPY) {
           const int north = (s + 1) % c->n_slabs, south = (s - 1 + c->n_slabs) % c->n_slabs;
-          HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, c->slab[north].ev_halo, 0));
-          HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, c->slab[south].ev_halo, 0));
+          if (q_wait(c, sl.comm, c->slab[north].ev_halo) != LBM_SUCCESS) return LBM_FAILURE;
+          if (q_wait(c, sl.comm, c->slab[south].ev_halo) != LBM_SUCCESS) return LBM_FAILURE;
         }
         hipEvent_t bdone = bound_events ? sl.ev_boundary : nullptr;  // B(m) done
         if (k) {
@@ -720,7 +892,7 @@ int issue_pass(lbm_ctx* c, int m, int tile, int k, bool accel_after, bool bound_
         } else {
           if (launch_step(c, s, sl.comm, 0, sl.rows - 1, 2, sl.blocks_main, accel_after, bdone) != LBM_SUCCESS) return LBM_FAILURE;
         }
-        if (!bdone) HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_boundary, sl.comm));
+        if (!bdone) return q_record(c, sl.ev_boundary, sl.comm);
         return LBM_SUCCESS;
       }) != LBM_SUCCESS)
     return LBM_FAILURE;
@@ -739,14 +911,15 @@ int issue_pass(lbm_ctx* c, int m, int tile, int k, bool accel_after, bool bound_
 
 // ---- hipGraph replay of the timestep loop ---------------------------------------------------------------------
 // A chunk = an even number of passes (so that it starts and ends on the same lattice buffer) and the reduce of
-// their partial sums, captured ONCE per lattice parity -- both streams of every slab, the halo exchange (RCCL
-// send/recv or device copies) inside the capture -- and replayed with one hipGraphLaunch (BASELINE.json
-// configs[4]: "double-buffered halos + hipGraph-captured timestep").  All launch arguments of a chunk are the same
+// their partial sums, built ONCE per lattice parity -- both streams of every slab, the halo exchange (RCCL
+// send/recv or device copies) inside the graph -- and replayed with one hipGraphLaunch (BASELINE.json
+// configs[4]: "double-buffered halos + hipGraph-captured timestep").  The graph is built node by node from the very
+// issue code of the stream pipeline (GraphBuilder: virtual streams and events); only an RCCL group is captured, on
+// its single comm stream, and enters as a child graph.  All launch arguments of a chunk are the same
 // every time except the index of the chunk's first step in tot_u, which the reduce kernel reads from device memory.
 // Every pass of a chunk applies the next step's acceleration, so a chunk is only replayed while at least one more
 // timestep follows it in the same lbm_run call.  A chunk begins with its own exchange X(0) and ends with every
 // stream joined, i.e. one exchange per chunk is not hidden behind interior rows (1 of 20-32).
-// The capture starts on slab 0's compute stream; every other stream joins it through an event.
 int chunk_passes(const lbm_ctx* c, int* steps_per_pass) {
   const int halo = (c->halo != HALO_SELF);
   const int adv = (!halo && c->tile_steps) ? c->tile_steps : (c->fuse2 ? c->pass_steps : 1);
@@ -758,63 +931,99 @@ int chunk_passes(const lbm_ctx* c, int* steps_per_pass) {
   return passes;
 }
 
-int capture_chunk(lbm_ctx* c, hipGraphExec_t* out) {
+// LBM_GRAPH_DUMP=<path>: the chunk's graph, checked before hipGraphInstantiate sees it -- node and edge
+// counts, self-edges, duplicate edges, and a topological sort (Kahn) that reports whether the graph is acyclic;
+// the graph itself goes to <path> as a dot file.  Returns false when the graph must not be instantiated.
+bool graph_is_sound(hipGraph_t graph, const char* dump_path) {
+  size_t n_nodes = 0, n_edges = 0;
+  if (hipGraphGetNodes(graph, nullptr, &n_nodes) != hipSuccess || hipGraphGetEdges(graph, nullptr, nullptr, &n_edges) != hipSuccess)
+    return true;  // cannot look: leave the verdict to the runtime
+  if (dump_path) fprintf(stderr, "lbm_hip graph: %zu nodes, %zu edges reported\n", n_nodes, n_edges);
+  std::vector<hipGraphNode_t> nodes(n_nodes), from(n_edges), to(n_edges);
+  if (n_nodes && hipGraphGetNodes(graph, nodes.data(), &n_nodes) != hipSuccess) return true;
+  if (n_edges && hipGraphGetEdges(graph, from.data(), to.data(), &n_edges) != hipSuccess) return true;
+  auto index_of = [&](hipGraphNode_t x) -> long {
+    for (size_t i = 0; i < n_nodes; i++) if (nodes[i] == x) return (long)i;
+    return -1;
+  };
+  std::vector<long> a(n_edges), b(n_edges);
+  std::vector<int> indeg(n_nodes, 0);
+  size_t self_edges = 0, dup_edges = 0, foreign = 0;
+  for (size_t e = 0; e < n_edges; e++) {
+    a[e] = index_of(from[e]);
+    b[e] = index_of(to[e]);
+    if (a[e] < 0 || b[e] < 0) { foreign++; continue; }
+    if (a[e] == b[e]) self_edges++;
+    for (size_t f = 0; f < e; f++) if (a[f] == a[e] && b[f] == b[e]) { dup_edges++; break; }
+    indeg[(size_t)b[e]]++;
+  }
+  // Kahn: every node of an acyclic graph is eventually freed
+  std::vector<long> ready;
+  for (size_t i = 0; i < n_nodes; i++) if (indeg[i] == 0) ready.push_back((long)i);
+  size_t sorted = 0;
+  while (!ready.empty()) {
+    const long v = ready.back();
+    ready.pop_back();
+    sorted++;
+    for (size_t e = 0; e < n_edges; e++)
+      if (a[e] == v && b[e] >= 0 && --indeg[(size_t)b[e]] == 0) ready.push_back(b[e]);
+  }
+  const bool acyclic = (sorted == n_nodes);
+  if (dump_path) {
+    fprintf(stderr, "lbm_hip: chunk graph: %zu nodes, %zu edges, %zu self-edges, %zu duplicate edges, %zu edges to foreign nodes, %s\n",
+            n_nodes, n_edges, self_edges, dup_edges, foreign, acyclic ? "acyclic" : "CYCLIC");
+    if (*dump_path && hipGraphDebugDotPrint(graph, dump_path, hipGraphDebugDotFlagsVerbose) != hipSuccess)
+      fprintf(stderr, "lbm_hip: hipGraphDebugDotPrint(%s) failed\n", dump_path);
+  }
+  return acyclic && self_edges == 0 && foreign == 0;
+}
+
+int build_chunk(lbm_ctx* c, hipGraphExec_t* out) {
   const bool halo = (c->halo != HALO_SELF);
   int adv;
   const int passes = chunk_passes(c, &adv);
   if (passes < 2) LBM_FAIL(LBM_FAILURE, "hipGraph chunk: no even number of passes fits");
+  for (int s = 1; s < c->n_slabs; s++)
+    if (c->slab[s].device != c->slab[0].device) LBM_FAIL(LBM_FAILURE, "hipGraph chunk: the slabs of one graph must share a device");
   const int tile = (!halo && c->tile_steps) ? c->tile_steps : 0;
   const int k = (!tile && c->fuse2) ? c->pass_steps : 0;
-  Slab& s0 = c->slab[0];
   const int saved_cur = c->cur, saved_fill = c->slot_fill;
-  hipGraph_t graph = nullptr;
-  HIP_TRY(LBM_FAILURE, hipSetDevice(s0.device));
-  HIP_TRY(LBM_FAILURE, hipStreamBeginCapture(s0.compute, halo ? hipStreamCaptureModeRelaxed : hipStreamCaptureModeThreadLocal));
+  GraphBuilder gb;
+  HIP_TRY(LBM_FAILURE, hipSetDevice(c->slab[0].device));
+  HIP_TRY(LBM_FAILURE, hipGraphCreate(&gb.graph, 0));
+  c->builder = &gb;
+  c->slot_fill = 0;
+  // Nothing is recorded yet: the first waits of pass 0 (I(-1), B(-1), the previous exchange) find no snapshot and
+  // add no dependency -- "ready when the chunk starts", which is what the launch stream's order guarantees.
   int rc = LBM_SUCCESS;
-  auto step = [&](hipError_t e) { if (e != hipSuccess && rc == LBM_SUCCESS) { raise_error(__LINE__, "HIP error during graph capture: %s", hipGetErrorString(e)); rc = LBM_FAILURE; } };
-  // fork: every other stream of the context joins the capture
-  step(hipEventRecord(s0.ev_fork, s0.compute));
+  for (int m = 0; m < passes && rc == LBM_SUCCESS; m++) rc = issue_pass(c, m, tile, k, true, false);
   for (int s = 0; s < c->n_slabs && rc == LBM_SUCCESS; s++) {
     Slab& sl = c->slab[s];
-    if (s > 0) step(hipStreamWaitEvent(sl.compute, s0.ev_fork, 0));
-    if (halo) step(hipStreamWaitEvent(sl.comm, s0.ev_fork, 0));
+    if (halo) rc = q_wait(c, sl.compute, sl.ev_boundary);  // the boundary rows' partials
+    const float* partials = sl.partials;
+    long stride = c->part_stride;
+    double* tot_u = sl.tot_u;
+    int zero = 0, fill = c->slot_fill;
+    const int* base_dev = sl.flushed_dev;
+    int* counter = sl.flushed_dev;
+    void* reduce_args[] = {&partials, &sl.slot_counts, &stride, &tot_u, &zero, &base_dev};
+    if (rc == LBM_SUCCESS)
+      rc = q_kernel(c, sl.compute, reinterpret_cast<const void*>(lbm::reduce_partials), dim3(c->slot_fill), dim3(lbm::kBlock), reduce_args);
+    void* advance_args[] = {&counter, &fill};
+    if (rc == LBM_SUCCESS)
+      rc = q_kernel(c, sl.compute, reinterpret_cast<const void*>(lbm::advance_counter), dim3(1), dim3(1), advance_args);
   }
-  c->slot_fill = 0;
-  if (halo && rc == LBM_SUCCESS) {
-    // pipeline events of pass 0 in a defined (captured) state
-    for (int s = 0; s < c->n_slabs && rc == LBM_SUCCESS; s++) {
-      Slab& sl = c->slab[s];
-      step(hipEventRecord(sl.ev_interior[1], sl.compute));
-      step(hipEventRecord(sl.ev_boundary, sl.comm));
-      if (c->halo == HALO_MEMCPY) step(hipEventRecord(sl.ev_halo, sl.comm));
-    }
-  }
-  for (int m = 0; m < passes && rc == LBM_SUCCESS; m++) rc = issue_pass(c, m, tile, k, true, false);
-  if (rc == LBM_SUCCESS) {
-    for (int s = 0; s < c->n_slabs; s++) {
-      Slab& sl = c->slab[s];
-      if (halo) step(hipStreamWaitEvent(sl.compute, sl.ev_boundary, 0));  // the boundary rows' partials
-      hipLaunchKernelGGL(lbm::reduce_partials, dim3(c->slot_fill), dim3(lbm::kBlock), 0, sl.compute, sl.partials,
-                         sl.slot_counts, c->part_stride, sl.tot_u, 0, (const int*)sl.flushed_dev);
-      hipLaunchKernelGGL(lbm::advance_counter, dim3(1), dim3(1), 0, sl.compute, sl.flushed_dev, c->slot_fill);
-      // join: back into slab 0's compute stream
-      if (halo) {
-        step(hipEventRecord(sl.ev_flush, sl.comm));
-        step(hipStreamWaitEvent(s0.compute, sl.ev_flush, 0));
-      }
-      if (s > 0) {
-        step(hipEventRecord(sl.ev_step, sl.compute));
-        step(hipStreamWaitEvent(s0.compute, sl.ev_step, 0));
-      }
-    }
-  }
-  const hipError_t end = hipStreamEndCapture(s0.compute, &graph);
+  c->builder = nullptr;
   c->cur = saved_cur;  // an even number of passes
   c->slot_fill = saved_fill;
-  if (rc != LBM_SUCCESS) { if (graph) (void)hipGraphDestroy(graph); return LBM_FAILURE; }
-  HIP_TRY(LBM_FAILURE, end);
-  const hipError_t inst = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
-  (void)hipGraphDestroy(graph);
+  if (rc != LBM_SUCCESS) { (void)hipGraphDestroy(gb.graph); return LBM_FAILURE; }
+  static const char* dump_path = getenv("LBM_GRAPH_DUMP");
+  if ((dump_path && !graph_is_sound(gb.graph, dump_path)) || env_int("LBM_GRAPH_DUMP_ONLY", 0)) {
+    (void)hipGraphDestroy(gb.graph);
+    LBM_FAIL(LBM_FAILURE, "hipGraph chunk: the graph is not instantiated (unsound, or LBM_GRAPH_DUMP_ONLY)");
+  }
+  const hipError_t inst = hipGraphInstantiate(out, gb.graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(gb.graph);
   HIP_TRY(LBM_FAILURE, inst);
   return LBM_SUCCESS;
 }
@@ -829,9 +1038,9 @@ int replay_chunks(lbm_ctx* c, int n_steps, int first_step, int* done) {
   if (n_chunks <= 0 || c->slot_fill != 0) return LBM_SUCCESS;
   Slab& s0 = c->slab[0];
   hipGraphExec_t& exec = s0.chunk_graph[c->cur];
-  if (!exec && capture_chunk(c, &exec) != LBM_SUCCESS) {
-    // e.g. a runtime that cannot capture across devices: go on launch by launch
-    fprintf(stderr, "lbm_hip: hipGraph capture failed (%s); continuing with stream launches\n", g_last_error);
+  if (!exec && build_chunk(c, &exec) != LBM_SUCCESS) {
+    // e.g. slabs on several devices: go on launch by launch
+    fprintf(stderr, "lbm_hip: hipGraph chunk not built (%s); continuing with stream launches\n", g_last_error);
     exec = nullptr;
     c->use_graph = 0;
     return LBM_SUCCESS;
@@ -1026,7 +1235,7 @@ void free_slab(Slab& sl) {
   // graphs that captured RCCL operations hold on to the communicator: they go first
   for (int i = 0; i < 2; i++)
     if (sl.chunk_graph[i]) { (void)hipGraphExecDestroy(sl.chunk_graph[i]); sl.chunk_graph[i] = nullptr; }
-  if (sl.nccl) ncclCommDestroy(sl.nccl);
+  if (sl.nccl && g_rccl.CommDestroy) g_rccl.CommDestroy(sl.nccl);
   for (int i = 0; i < 2; i++) if (sl.lat_alloc[i]) (void)hipFree(sl.lat_alloc[i]);
   if (sl.mask_alloc) (void)hipFree(sl.mask_alloc);
   if (sl.partials) (void)hipFree(sl.partials);
@@ -1470,9 +1679,12 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
     // one process per GPU: the communicator spans the ranks (also used for the av_vels reduce)
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof(id));
-    if (hipSetDevice(c->slab[0].device) != hipSuccess ||
-        ncclCommInitRank(&c->slab[0].nccl, world, id, rank) != ncclSuccess) {
-      raise_error(__LINE__, "lbm_create_rank: ncclCommInitRank failed");
+    RcclApi* nc = rccl();
+    ncclResult_t res = ncclSuccess;
+    if (!nc || hipSetDevice(c->slab[0].device) != hipSuccess ||
+        (res = nc->CommInitRank(&c->slab[0].nccl, world, id, rank)) != ncclSuccess) {
+      raise_error(__LINE__, "lbm_create_rank: ncclCommInitRank(rank %d of %d) failed: %s", rank, world,
+                  nc ? nc->GetErrorString(res) : g_rccl_error);
       lbm_destroy(c);
       return nullptr;
     }
@@ -1480,8 +1692,11 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
     ncclComm_t comms[kMaxSlabs];
     int devs[kMaxSlabs];
     for (int s = 0; s < n_slabs; s++) devs[s] = c->slab[s].device;
-    if (ncclCommInitAll(comms, n_slabs, devs) != ncclSuccess) {
-      raise_error(__LINE__, "lbm_create: ncclCommInitAll failed (set LBM_HALO=memcpy when slabs share a device)");
+    RcclApi* nc = rccl();
+    ncclResult_t res = ncclSuccess;
+    if (!nc || (res = nc->CommInitAll(comms, n_slabs, devs)) != ncclSuccess) {
+      raise_error(__LINE__, "lbm_create: ncclCommInitAll failed: %s (set LBM_HALO=memcpy when slabs share a device)",
+                  nc ? nc->GetErrorString(res) : g_rccl_error);
       lbm_destroy(c);
       return nullptr;
     }
@@ -1505,7 +1720,7 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
       long long* dev = reinterpret_cast<long long*>(sl.scratch);
       if (hipSetDevice(sl.device) != hipSuccess ||
           hipMemcpy(dev, &fluid, sizeof(fluid), hipMemcpyHostToDevice) != hipSuccess ||
-          ncclAllReduce(dev, dev, 1, ncclInt64, ncclSum, sl.nccl, sl.comm) != ncclSuccess ||
+          !rccl() || g_rccl.AllReduce(dev, dev, 1, ncclInt64, ncclSum, sl.nccl, sl.comm) != ncclSuccess ||
           hipStreamSynchronize(sl.comm) != hipSuccess ||
           hipMemcpy(&fluid, dev, sizeof(fluid), hipMemcpyDeviceToHost) != hipSuccess) {
         raise_error(__LINE__, "lbm_create_rank: all-reduce of the fluid-cell count failed");
@@ -1533,7 +1748,7 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
   // (host issue 11.1 vs 11.6 us per step for a rank with RCCL self-exchange at 256^2: the runtime still enqueues every
   // node) and hipGraphInstantiate overflows its stack on the larger pipelines (3+ slabs with device-copy halos, a
   // rank's 20-pass chunk at 8192x1024) -- profiles/r02_tuning.md.  The device-copy transport never uses it.
-  if (c->halo != HALO_SELF && (!getenv("LBM_GRAPH") || c->halo != HALO_RCCL)) c->use_graph = 0;
+  if (c->halo != HALO_SELF && (!getenv("LBM_GRAPH") || c->halo == HALO_HOST)) c->use_graph = 0;
   if (want_team) {
     c->use_graph = 0;
     c->team = new SlabTeam();
@@ -1607,8 +1822,37 @@ int lbm_rccl_unique_id(void* id_out) {
   if (!id_out) LBM_FAIL(LBM_FAILURE, "lbm_rccl_unique_id: NULL output");
   static_assert(sizeof(ncclUniqueId) == LBM_RCCL_ID_BYTES, "RCCL unique id size");
   ncclUniqueId id;
-  NCCL_TRY(LBM_FAILURE, ncclGetUniqueId(&id));
+  RCCL_OR_FAIL(LBM_FAILURE);
+  NCCL_TRY(LBM_FAILURE, rc_api_->GetUniqueId(&id));
   memcpy(id_out, &id, sizeof(id));
+  return LBM_SUCCESS;
+}
+
+int lbm_rccl_info(const lbm_ctx* c, lbm_rccl_status* out) {
+  if (!out) LBM_FAIL(LBM_FAILURE, "lbm_rccl_info: NULL output");
+  memset(out, 0, sizeof(*out));
+  // without a context: bind the library (as the first multi-GPU create would) and describe it; with one: describe
+  // what the context uses, binding nothing on behalf of a context that never needed RCCL
+  RcclApi* nc = nullptr;
+  if (!c) {
+    nc = rccl();
+    if (!nc) LBM_FAIL(LBM_FAILURE, "RCCL is not available: %s", g_rccl_error);
+  } else {
+    for (int s = 0; s < c->n_slabs; s++) if (c->slab[s].nccl) out->n_comms++;
+    if (out->n_comms > 0) nc = rccl();
+  }
+  if (!nc) return LBM_SUCCESS;
+  out->loaded = 1;
+  strncpy(out->library, nc->path, sizeof(out->library) - 1);
+  NCCL_TRY(LBM_FAILURE, nc->GetVersion(&out->version));
+  if (c && out->n_comms > 0) {
+    for (int s = 0; s < c->n_slabs; s++)
+      if (c->slab[s].nccl) {
+        NCCL_TRY(LBM_FAILURE, nc->CommCount(c->slab[s].nccl, &out->nranks));
+        NCCL_TRY(LBM_FAILURE, nc->CommUserRank(c->slab[s].nccl, &out->rank));
+        break;
+      }
+  }
   return LBM_SUCCESS;
 }
 
@@ -1638,12 +1882,37 @@ lbm_ctx* lbm_create_rank_rows(const lbm_params* params, const int* obstacle_rows
   return create_common(params, obst, cells_rows_aos, 1, math_mode, rank, world_size, unique_id, device);
 }
 
+static bool hosted_args_ok(int rank, int world_size, const lbm_host_comm* comm) {
+  if (world_size < 1 || rank < 0 || rank >= world_size) {
+    raise_error(__LINE__, "lbm_create_rank_hosted: bad rank %d of %d", rank, world_size);
+    return false;
+  }
+  if (!comm || !comm->exchange || !comm->allreduce_sum) {
+    raise_error(__LINE__, "lbm_create_rank_hosted: the exchange and all-reduce callbacks are required");
+    return false;
+  }
+  return true;
+}
+
 lbm_ctx* lbm_create_rank_hosted(const lbm_params* params, const int* obstacles, const float* cells_aos,
                                 int rank, int world_size, const lbm_host_comm* comm, int device, int math_mode) {
-  if (world_size < 1 || rank < 0 || rank >= world_size) LBM_FAIL(nullptr, "lbm_create_rank_hosted: bad rank %d of %d", rank, world_size);
-  if (!comm || !comm->exchange || !comm->allreduce_sum) LBM_FAIL(nullptr, "lbm_create_rank_hosted: the exchange and all-reduce callbacks are required");
+  if (!hosted_args_ok(rank, world_size, comm)) return nullptr;
   const ObstacleSource obst = {OBST_GLOBAL, obstacles, 0, 0, false};
   return create_common(params, obst, cells_aos, 1, math_mode, rank, world_size, nullptr, device, comm);
+}
+
+lbm_ctx* lbm_create_rank_hosted_rows(const lbm_params* params, const int* obstacle_rows, const float* cells_rows_aos,
+                                     int rank, int world_size, const lbm_host_comm* comm, int device, int math_mode) {
+  if (!hosted_args_ok(rank, world_size, comm)) return nullptr;
+  const ObstacleSource obst = {OBST_ROWS, obstacle_rows, 0, 0, true};
+  return create_common(params, obst, cells_rows_aos, 1, math_mode, rank, world_size, nullptr, device, comm);
+}
+
+lbm_ctx* lbm_create_rank_hosted_tiled(const lbm_params* params, const int* tile, int tile_nx, int tile_ny,
+                                      int rank, int world_size, const lbm_host_comm* comm, int device, int math_mode) {
+  if (!hosted_args_ok(rank, world_size, comm)) return nullptr;
+  const ObstacleSource obst = {OBST_TILE, tile, tile_nx, tile_ny, false};
+  return create_common(params, obst, nullptr, 1, math_mode, rank, world_size, nullptr, device, comm);
 }
 
 lbm_ctx* lbm_create_rank_tiled(const lbm_params* params, const int* tile, int tile_nx, int tile_ny,
@@ -1745,7 +2014,8 @@ int lbm_read_av_vels(lbm_ctx* c, float* out, int n) {
     double* tmp = sl.reduce_buf;  // allocated once at create: nothing to leak on an error return
     HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
     HIP_TRY(LBM_FAILURE, hipMemcpy(tmp, total.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
-    NCCL_TRY(LBM_FAILURE, ncclAllReduce(tmp, tmp, (size_t)n, ncclDouble, ncclSum, sl.nccl, sl.comm));
+    RCCL_OR_FAIL(LBM_FAILURE);
+    NCCL_TRY(LBM_FAILURE, rc_api_->AllReduce(tmp, tmp, (size_t)n, ncclDouble, ncclSum, sl.nccl, sl.comm));
     HIP_TRY(LBM_FAILURE, hipStreamSynchronize(sl.comm));
     HIP_TRY(LBM_FAILURE, hipMemcpy(total.data(), tmp, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
   }
@@ -1835,7 +2105,8 @@ static int lattice_totals(lbm_ctx* c, double* speed, double* mass) {
     Slab& sl = c->slab[0];
     HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
     HIP_TRY(LBM_FAILURE, hipMemcpy(sl.scratch, tot, 2 * sizeof(double), hipMemcpyHostToDevice));
-    NCCL_TRY(LBM_FAILURE, ncclAllReduce(sl.scratch, sl.scratch, 2, ncclDouble, ncclSum, sl.nccl, sl.comm));
+    RCCL_OR_FAIL(LBM_FAILURE);
+    NCCL_TRY(LBM_FAILURE, rc_api_->AllReduce(sl.scratch, sl.scratch, 2, ncclDouble, ncclSum, sl.nccl, sl.comm));
     HIP_TRY(LBM_FAILURE, hipStreamSynchronize(sl.comm));
     HIP_TRY(LBM_FAILURE, hipMemcpy(tot, sl.scratch, 2 * sizeof(double), hipMemcpyDeviceToHost));
   }

@@ -25,7 +25,21 @@ def free_port():
         return s.getsockname()[1]
 
 
-def rank_main(rank, world, port, case, steps_list, out_dir, env):
+def make_case(lbm, oracle, case, form):
+    """(params, global obstacle map, global initial lattice) of a test case; the tile form starts from the uniform
+    equilibrium on a grid twice the data set's height (the tile repeated)."""
+    import conftest
+    from test_gpu_parity import random_case
+    if isinstance(case, str):
+        p, ob = conftest.dataset(case)
+        if form == "tile":
+            p.ny *= 2
+            ob = np.concatenate([ob, ob])
+        return p, ob, oracle.init_cells(p)
+    return random_case(lbm, *case, walls=False)
+
+
+def rank_main(rank, world, port, case, steps_list, out_dir, env, form="global"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.update(env or {})
@@ -36,11 +50,7 @@ def rank_main(rank, world, port, case, steps_list, out_dir, env):
         from test_gpu_parity import random_case
         lbm = conftest.load_package()
         oracle = oracle_binding.load()
-        if isinstance(case, str):
-            p, ob = conftest.dataset(case)
-            cells = oracle.init_cells(p)
-        else:
-            p, ob, cells = random_case(lbm, *case, walls=False)
+        p, ob, cells = make_case(lbm, oracle, case, form)
 
         def exchange(plan, bufs):
             ops = []
@@ -54,9 +64,23 @@ def rank_main(rank, world, port, case, steps_list, out_dir, env):
             dist.all_reduce(torch.from_numpy(values), op=dist.ReduceOp.SUM)
 
         total = sum(steps_list)
-        with lbm.Engine(p, ob, cells, rank=rank, world_size=world, device=0, host_comm=(exchange, allreduce)) as eng:
+        first, count = lbm.partition_rows(p.ny, world, rank)
+        if form == "rows":
+            # the reference's scatter (MPI_Waitall/d2q9-bgk.c:816-842): this rank's rows only, plus the periodic
+            # neighbour rows a multi-step pass relaxes redundantly
+            h = lbm.MASK_HALO_ROWS
+            idx = np.arange(first - h, first + count + h) % p.ny
+            create = dict(obstacles=ob[idx], cells=cells[first:first + count], local_rows=True)
+        elif form == "tile":
+            create = dict(obstacles=ob[:p.ny // 2], cells=None, tiled=True)
+        else:
+            create = dict(obstacles=ob, cells=cells)
+        with lbm.Engine(p, create["obstacles"], create["cells"], rank=rank, world_size=world, device=0,
+                        host_comm=(exchange, allreduce), tiled=create.get("tiled", False),
+                        local_rows=create.get("local_rows", False)) as eng:
             info = eng.info()
             assert (info["world_rank"], info["world_size"]) == (rank, world)
+            assert (info["row_first"], info["row_count"]) == (first, count)
             assert info["fluid_cells"] == int((ob == 0).sum())          # all-reduced device-side count
             for n in steps_list:
                 eng.run(n)
@@ -84,25 +108,25 @@ def rank_main(rank, world, port, case, steps_list, out_dir, env):
 FOUR_STEP = {"LBM_FUSE2": "1", "LBM_LANE_CELLS": "4"}
 
 
-@pytest.mark.parametrize("world,case,steps_list,env,depth", [
-    (2, "128x256", [76], None, 3),                     # default at this size: three-step passes on one pair per lane
-    (3, "128x256", [40, 1, 22], None, 3),              # run in pieces
-    (2, "128x256", [75], {"LBM_PASS_STEPS": "2"}, 2),  # two-step passes, odd tail
-    (2, "128x256", [77], FOUR_STEP, 4),                # four-step packed passes + a one-step tail; 2 ranks: north == south
-    (3, "128x256", [31, 2, 44], FOUR_STEP, 4),
-    (3, (512, 50, 5), [26], FOUR_STEP, 4),             # random lattice, uneven slabs (17, 17, 16 rows), both wraps live
-    (2, (260, 33, 6), [9], None, 3),                   # 4 | nx but nx % 64 != 0
+@pytest.mark.parametrize("world,case,steps_list,env,depth,form", [
+    (2, "128x256", [76], None, 3, "global"),           # default at this size: three-step passes on one pair per lane
+    (3, "128x256", [40, 1, 22], None, 3, "global"),    # run in pieces
+    (2, "128x256", [75], {"LBM_PASS_STEPS": "2"}, 2, "global"),  # two-step passes, odd tail
+    (2, "128x256", [77], FOUR_STEP, 4, "global"),      # four-step packed passes + a one-step tail; 2 ranks: north == south
+    (3, "128x256", [31, 2, 44], FOUR_STEP, 4, "global"),
+    (3, (512, 50, 5), [26], FOUR_STEP, 4, "global"),   # random lattice, uneven slabs (17, 17, 16 rows), both wraps live
+    (2, (260, 33, 6), [9], None, 3, "global"),         # 4 | nx but nx % 64 != 0
+    # lbm_create_rank_hosted_rows: every rank hands over its own rows only (+ the periodic neighbour rows of the mask)
+    (3, (512, 50, 5), [26], FOUR_STEP, 4, "rows"),
+    (2, (260, 33, 6), [9], None, 3, "rows"),
+    (3, "128x256", [40, 1, 22], None, 3, "rows"),
+    # lbm_create_rank_hosted_tiled: the 128x128 map repeated over a 128x256 grid, expanded on each rank's device
+    (3, "128x128", [37], None, 3, "tile"),
 ])
-def test_hosted_ranks_equal_single_domain(tmp_path, oracle, lbm, world, case, steps_list, env, depth):
+def test_hosted_ranks_equal_single_domain(tmp_path, oracle, lbm, world, case, steps_list, env, depth, form):
     torch.set_num_threads(1)
-    mp.spawn(rank_main, args=(world, free_port(), case, steps_list, str(tmp_path), env), nprocs=world, join=True)
-    import conftest
-    from test_gpu_parity import random_case
-    if isinstance(case, str):
-        p, ob = conftest.dataset(case)
-        ref = oracle.init_cells(p)
-    else:
-        p, ob, ref = random_case(lbm, *case, walls=False)
+    mp.spawn(rank_main, args=(world, free_port(), case, steps_list, str(tmp_path), env, form), nprocs=world, join=True)
+    p, ob, ref = make_case(lbm, oracle, case, form)
     ref_av = oracle.run(p, ref, ob, sum(steps_list))
     assert int(np.load(tmp_path / "depth.npy")[0]) == depth
     got = np.load(tmp_path / "lattice.npy")
