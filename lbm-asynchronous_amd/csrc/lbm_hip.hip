@@ -924,7 +924,7 @@ int chunk_passes(const lbm_ctx* c, int* steps_per_pass) {
   const int halo = (c->halo != HALO_SELF);
   const int adv = (!halo && c->tile_steps) ? c->tile_steps : (c->fuse2 ? c->pass_steps : 1);
   int passes = kPartSlots / adv;
-  static const int cap = env_int("LBM_GRAPH_PASSES", 0);  // experiments: shorter chunks
+  const int cap = env_int("LBM_GRAPH_PASSES", 0);  // experiments and tests: shorter chunks
   if (cap > 0 && passes > cap) passes = cap;
   passes -= passes & 1;
   *steps_per_pass = adv;
@@ -1017,7 +1017,7 @@ int build_chunk(lbm_ctx* c, hipGraphExec_t* out) {
   c->cur = saved_cur;  // an even number of passes
   c->slot_fill = saved_fill;
   if (rc != LBM_SUCCESS) { (void)hipGraphDestroy(gb.graph); return LBM_FAILURE; }
-  static const char* dump_path = getenv("LBM_GRAPH_DUMP");
+  const char* dump_path = getenv("LBM_GRAPH_DUMP");
   if ((dump_path && !graph_is_sound(gb.graph, dump_path)) || env_int("LBM_GRAPH_DUMP_ONLY", 0)) {
     (void)hipGraphDestroy(gb.graph);
     LBM_FAIL(LBM_FAILURE, "hipGraph chunk: the graph is not instantiated (unsound, or LBM_GRAPH_DUMP_ONLY)");

@@ -1,6 +1,8 @@
 """The rank pipeline (RCCL self-exchange) with and without hipGraph replay (LBM_GRAPH): same fields, time per step.
-python tools/graph_rank.py NXxNY steps   (system RCCL, no torch in the process)"""
+python tools/graph_rank.py NXxNY steps [--torch-first]   (without the flag: ROCm's RCCL, no torch in the process)"""
 import os, sys, time
+if "--torch-first" in sys.argv:
+    import torch
 sys.path.insert(0, "tests")
 import numpy as np
 import conftest
@@ -14,7 +16,7 @@ out = {}
 for graph in ("0", "1"):
     os.environ["LBM_GRAPH"] = graph
     with lbm.Engine(p, tile, None, rank=0, world_size=1, unique_id=lbm.rccl_unique_id(), device=0, tiled=True) as eng:
-        print("graph", graph, eng.info(), flush=True)
+        print("graph", graph, eng.info(), eng.rccl_info()["library"], flush=True)
         eng.run(steps); eng.sync()
         t0 = time.perf_counter(); eng.run(steps); t1 = time.perf_counter(); eng.sync(); t2 = time.perf_counter()
         out[graph] = eng.final_state()["pressure"].copy()
