@@ -572,6 +572,14 @@ def main():
                                       "warmup": wu, "repeats": 3, "steps_per_launch": inf["steps_per_launch"],
                                       "band_rows": inf["band_rows"], "lane_cells": inf["lane_cells"],
                                       "results_finite": fin, "note": note}
+                rec = pmc_record(gx, gy, args.math, inf) if world == 1 else None
+                if rec:     # committed PMC profile of exactly this kernel geometry (not measured in this run)
+                    also[f"{gx}x{gy}"]["limiter"] = {"valu_busy": rec.get("valu_busy"), "issue_busy": rec.get("issue_busy"),
+                                                     "lane_instructions_per_update": rec.get("lane_instructions_per_update"),
+                                                     "wave_cycles_share": rec.get("wave_cycles_share"),
+                                                     "what": rec.get("limiter_note"),
+                                                     "source": f"committed profile {rec.get('source')} at commit {rec.get('commit')}, "
+                                                               f"key {rec['key']}; NOT measured in this run"}
             except Exception as exc:            # never lose the main line over an extra one
                 also[f"{gx}x{gy}"] = {"error": str(exc)}
                 if use_rank_api:
