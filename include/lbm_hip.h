@@ -85,7 +85,11 @@ typedef struct {
   int    band_rows;      /* launch geometry of the multi-step stream kernel: rows one wave sweeps ... */
   int    lane_cells;     /* ... and cells per lane (4 or 2); 0 / 0 when another kernel is the main one */
   int    nontemporal;    /* 1: the step kernels store with the nontemporal hint */
-  int    graph_steps;    /* timesteps one captured hipGraph replays (0: loop issued launch by launch) */
+  int    graph_steps;    /* timesteps one hipGraph chunk replays (0: loop issued launch by launch) */
+  int    resident_steps; /* > 0: lbm_run calls of at least resident_min_steps timesteps run as launches of the resident
+                            kernel (lattice in registers, up to this many timesteps per launch); single periodic slabs of
+                            at most 1024 x 4*CUs cells */
+  int    resident_min_steps;
 } lbm_info;
 
 /* ---- error handling -------------------------------------------------------------------- */

@@ -63,7 +63,8 @@ class _CInfo(ctypes.Structure):
                 ("math_mode", ctypes.c_int), ("world_rank", ctypes.c_int),
                 ("world_size", ctypes.c_int), ("steps_per_launch", ctypes.c_int),
                 ("halo_mode", ctypes.c_int), ("band_rows", ctypes.c_int), ("lane_cells", ctypes.c_int),
-                ("nontemporal", ctypes.c_int), ("graph_steps", ctypes.c_int)]
+                ("nontemporal", ctypes.c_int), ("graph_steps", ctypes.c_int),
+                ("resident_steps", ctypes.c_int), ("resident_min_steps", ctypes.c_int)]
 
 
 class _CRcclStatus(ctypes.Structure):

@@ -166,6 +166,9 @@ struct Slab {
   double* scratch = nullptr;  // 2 x kSumBlocks doubles for lattice_sums
   double* reduce_buf = nullptr;  // ranked contexts: capacity doubles for the av_vels all-reduce
   int* flushed_dev = nullptr; // graph replay: index of the first step of the chunk being reduced
+  unsigned long long* res_gran = nullptr;  // resident kernel: seam granules [2][bands][2][3][nx]
+  float* res_part = nullptr;               // resident kernel: per-band partial sums of a launch, [kResidentChunk][bands]
+  int* res_status = nullptr;               // resident kernel: 0, or the reason a workgroup gave up
   hipGraphExec_t chunk_graph[2] = {nullptr, nullptr};  // kPartSlots timesteps + their reduce, by lattice parity
   hipStream_t compute = nullptr, comm = nullptr;
   hipEvent_t ev_boundary = nullptr, ev_halo = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
@@ -182,6 +185,7 @@ struct Slab {
 };
 
 constexpr int kSumBlocks = 1024;
+constexpr int kResidentChunk = 4096;  // most timesteps one launch of the resident kernel advances
 // step_tile instantiations: own cells per workgroup (tw x th), halo depth = most timesteps per launch, threads
 struct TileShape { int tw, th, kmax, threads; void (*exact)(const lbm::TileArgs); void (*fast)(const lbm::TileArgs); };
 #define LBM_TILE_SHAPE(TW, TH, K, T) {TW, TH, K, T, lbm::step_tile<0, TW, TH, K, T>, lbm::step_tile<1, TW, TH, K, T>}
@@ -347,6 +351,11 @@ struct lbm_ctx {
   SlabTeam* team = nullptr;         // one issuing thread per slab (one-process multi-GPU), or null
   int use_graph = 0;                // replay chunks of an even number of passes + their reduce as one hipGraph each
   GraphBuilder* builder = nullptr;  // non-null while a chunk is being built: launches become graph nodes
+  int resident = 0;                 // single periodic slab that fits the chip's registers: lbm_run calls of at least
+  int resident_min_steps = 16;      // ... this many timesteps run as launches of the resident kernel (lbm::resident_band)
+  int resident_bands = 0;           // its workgroups (bands of kResidentRows rows)
+  long long resident_timeout = 0;   // bound of one halo wait, wall-clock ticks
+  bool resident_used = false;       // a launch is in flight / unchecked: lbm_sync reads its status
   int tile_steps = 0;               // > 0: single slab advanced by the LDS-tile kernel, this many steps per launch
   int tile_shape = 0;               // index into kTileShapes
 };
@@ -1078,6 +1087,49 @@ int replay_chunks(lbm_ctx* c, int n_steps, int first_step, int* done) {
 
 int run_steps_stale(lbm_ctx* c, int n_steps, float* kernel_ms);
 
+// The timestep loop of a cache-resident single slab: launches of lbm::resident_band, each advancing up to
+// kResidentChunk timesteps with the lattice in registers (SerialCode/d2q9-bgk.c:166-170 as ONE launch), each followed
+// by the reduce of its per-band partial sums.  The caller has applied the first step's accelerate_flow.
+int run_resident(lbm_ctx* c, int n_steps) {
+  Slab& sl = c->slab[0];
+  HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+  for (int t = 0; t < n_steps;) {
+    const int n = (n_steps - t < kResidentChunk) ? n_steps - t : kResidentChunk;
+    lbm::ResidentArgs a;
+    a.src = sl.lat[c->cur];
+    a.dst = sl.lat[c->cur ^ 1];
+    a.mask = sl.mask;
+    a.plane_stride = c->plane_stride;
+    a.row_pitch = c->row_pitch;
+    a.pitch = c->pitch;
+    a.nx = c->p.nx;
+    a.ny = sl.rows;
+    a.n_steps = n;
+    a.accel_row = sl.accel_row;
+    a.accel_last = (t + n < n_steps) ? 1 : 0;
+    a.omega = c->p.omega;
+    a.a1 = c->p.density * c->p.accel / 9.f;
+    a.a2 = c->p.density * c->p.accel / 36.f;
+    a.gran = sl.res_gran;
+    a.epoch0 = (unsigned)(c->steps_done + t);
+    a.partials = sl.res_part;
+    a.status = sl.res_status;
+    a.timeout_ticks = c->resident_timeout;
+    a.absent_band = env_int("LBM_RESIDENT_ABSENT_BAND", -1);  // tests of the give-up path
+    void* args[] = {&a};
+    const void* fn = (c->p.nx > 512) ? reinterpret_cast<const void*>(lbm::resident_band<1024>)
+                                     : reinterpret_cast<const void*>(lbm::resident_band<512>);
+    HIP_TRY(LBM_FAILURE, hipLaunchKernel(fn, dim3(c->resident_bands), dim3(c->p.nx), args, 0, sl.compute));
+    hipLaunchKernelGGL(lbm::reduce_band_partials, dim3(n), dim3(64), 0, sl.compute, (const float*)sl.res_part,
+                       c->resident_bands, sl.tot_u, c->steps_done + t);
+    HIP_TRY(LBM_FAILURE, hipGetLastError());
+    c->cur ^= 1;
+    t += n;
+  }
+  c->resident_used = true;
+  return LBM_SUCCESS;
+}
+
 int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
   if (!c) LBM_FAIL(LBM_FAILURE, "lbm_run: null context");
   if (n_steps < 0) LBM_FAIL(LBM_FAILURE, "lbm_run: negative step count");
@@ -1107,6 +1159,12 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
         return LBM_SUCCESS;
       }) != LBM_SUCCESS)
     return LBM_FAILURE;
+
+  if (c->resident && n_steps >= c->resident_min_steps) {
+    if (run_resident(c, n_steps) != LBM_SUCCESS) return LBM_FAILURE;
+    c->steps_done += n_steps;
+    return kernel_ms ? read_step_timing(c, n_steps, kernel_ms) : LBM_SUCCESS;
+  }
 
   int flushed_upto = c->steps_done;
   int t_first = 0;
@@ -1243,7 +1301,9 @@ void free_slab(Slab& sl) {
   if (sl.scratch) (void)hipFree(sl.scratch);
   if (sl.reduce_buf) (void)hipFree(sl.reduce_buf);
   if (sl.flushed_dev) (void)hipFree(sl.flushed_dev);
-  for (int i = 0; i < 2; i++) if (sl.chunk_graph[i]) (void)hipGraphExecDestroy(sl.chunk_graph[i]);
+  if (sl.res_gran) (void)hipFree(sl.res_gran);
+  if (sl.res_part) (void)hipFree(sl.res_part);
+  if (sl.res_status) (void)hipFree(sl.res_status);
   if (sl.ev_boundary) (void)hipEventDestroy(sl.ev_boundary);
   if (sl.ev_halo) (void)hipEventDestroy(sl.ev_halo);
   for (int i = 0; i < 2; i++) if (sl.ev_interior[i]) (void)hipEventDestroy(sl.ev_interior[i]);
@@ -1295,6 +1355,15 @@ int build_slab(lbm_ctx* c, int s, const ObstacleSource& obst, const float* cells
   HIP_TRY(LBM_FAILURE, hipMemsetAsync(sl.tot_u, 0, (size_t)(c->capacity > 0 ? c->capacity : 1) * sizeof(double), sl.compute));
   HIP_TRY(LBM_FAILURE, hipMalloc(&sl.scratch, 2 * kSumBlocks * sizeof(double)));
   HIP_TRY(LBM_FAILURE, hipMalloc(&sl.flushed_dev, sizeof(int)));
+  if (c->resident) {
+    // granules start at tag 0 = "nothing"; tags are global step indices + 1, so they never need clearing again
+    const size_t gran_bytes = 2UL * c->resident_bands * 2 * 3 * p.nx * sizeof(unsigned long long);
+    HIP_TRY(LBM_FAILURE, hipMalloc(&sl.res_gran, gran_bytes));
+    HIP_TRY(LBM_FAILURE, hipMemsetAsync(sl.res_gran, 0, gran_bytes, sl.compute));
+    HIP_TRY(LBM_FAILURE, hipMalloc(&sl.res_part, (size_t)kResidentChunk * c->resident_bands * sizeof(float)));
+    HIP_TRY(LBM_FAILURE, hipMalloc(&sl.res_status, sizeof(int)));
+    HIP_TRY(LBM_FAILURE, hipMemsetAsync(sl.res_status, 0, sizeof(int), sl.compute));
+  }
   if (c->ranked) HIP_TRY(LBM_FAILURE, hipMalloc(&sl.reduce_buf, (size_t)(c->capacity > 0 ? c->capacity : 1) * sizeof(double)));
 
   // obstacle mask: uint8 (rows + 2*kMaskHalo) x pitch with the (periodic) neighbour rows beyond the slab, which a
@@ -1660,6 +1729,37 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
   }
   c->part_stride = round_up(max_blocks, 64);
 
+  // Resident kernel (lbm::resident_band): one launch advances up to kResidentChunk timesteps with the lattice in
+  // registers, bands of 4 rows x the full width per workgroup, seam rows through L2 granules.  For single periodic
+  // slabs whose bands are all co-resident (at most one workgroup per CU of the device) and whose rows are one lane
+  // per cell wide: the reference's own data sets (128x128 ... 1024x1024).  Both math modes run it (its arithmetic is
+  // the exact one, which meets the fast mode's tolerance and is the faster kernel at these sizes).  Asking for
+  // another kernel by any of the selection knobs leaves it off unless LBM_RESIDENT=1 says otherwise.
+  if (!halo_on && n_slabs == 1) {
+    static const char* const selectors[] = {"LBM_FUSE2", "LBM_VEC4", "LBM_TILE_STEPS", "LBM_TILE_SHAPE", "LBM_LANE_CELLS", "LBM_PASS_STEPS",
+                                            "LBM_PACKED", "LBM_BAND_ROWS", "LBM_GRAPH", "LBM_STEPK", "LBM_LDS_WINDOWS", "LBM_PREFETCH",
+                                            "LBM_XCD_CHUNK", "LBM_NEIGH", "LBM_SNAKE", "LBM_NTS"};
+    bool other_kernel = false;
+    for (const char* name : selectors) other_kernel = other_kernel || getenv(name) != nullptr;
+    const int nx = params->nx, ny = params->ny;
+    const bool shape_ok = nx % 64 == 0 && nx >= 64 && nx <= 1024 && ny % lbm::kResidentRows == 0 && ny >= 2 * lbm::kResidentRows;
+    if (shape_ok && env_int("LBM_RESIDENT", other_kernel ? 0 : 1)) {
+      const int dev = c->slab[0].device;
+      int cus = 0, per_cu = 0;
+      const void* fn = (nx > 512) ? reinterpret_cast<const void*>(lbm::resident_band<1024>)
+                                  : reinterpret_cast<const void*>(lbm::resident_band<512>);
+      if (hipSetDevice(dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, nx, 0) == hipSuccess && per_cu >= 1 &&
+          ny / lbm::kResidentRows <= cus) {
+        c->resident = 1;
+        c->resident_bands = ny / lbm::kResidentRows;
+        c->resident_min_steps = env_int("LBM_RESIDENT_MIN_STEPS", 16);
+        if (c->resident_min_steps < 1) c->resident_min_steps = 1;
+        c->resident_timeout = (long long)env_int("LBM_RESIDENT_TIMEOUT_MS", 2000) * 100000LL;  // wall_clock64(): 100 MHz
+      }
+    }
+  }
+
   for (int s = 0; s < n_slabs; s++)
     if (build_slab(c, s, obst, cells_aos) != LBM_SUCCESS) {
       lbm_destroy(c);
@@ -1966,6 +2066,8 @@ int lbm_get_info(const lbm_ctx* c, lbm_info* out) {
     const int passes = chunk_passes(c, &adv);
     out->graph_steps = (c->use_graph && !stale) ? passes * adv : 0;
   }
+  out->resident_steps = c->resident ? kResidentChunk : 0;
+  out->resident_min_steps = c->resident ? c->resident_min_steps : 0;
   return LBM_SUCCESS;
 }
 
@@ -1989,6 +2091,17 @@ int lbm_sync(lbm_ctx* c) {
     HIP_TRY(LBM_FAILURE, hipSetDevice(c->slab[s].device));
     HIP_TRY(LBM_FAILURE, hipStreamSynchronize(c->slab[s].compute));
     HIP_TRY(LBM_FAILURE, hipStreamSynchronize(c->slab[s].comm));
+  }
+  if (c->resident_used) {
+    // did every workgroup of the resident kernel get its neighbours' rows in time?
+    int status = 0;
+    HIP_TRY(LBM_FAILURE, hipMemcpy(&status, c->slab[0].res_status, sizeof(status), hipMemcpyDeviceToHost));
+    c->resident_used = false;
+    if (status != 0)
+      LBM_FAIL(LBM_FAILURE, "the resident kernel gave up waiting for a neighbouring band after %.0f ms (status %d): its %d workgroups "
+               "were not all running at once -- is another process using the device?  The lattice of this context is no "
+               "longer valid; LBM_RESIDENT=0 selects the launch-per-pass kernels, LBM_RESIDENT_TIMEOUT_MS moves the bound",
+               (double)c->resident_timeout / 1e5, status, c->resident_bands);
   }
   return LBM_SUCCESS;
 }

@@ -1417,6 +1417,275 @@ __global__ __launch_bounds__(THREADS) void step_tile(const TileArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Resident lattice: ONE launch advances the whole (single, periodic) slab by many timesteps with the lattice kept
+// in registers -- the form for cache-resident grids (the reference's own data sets, 128^2 ... 1024^2 x 20 000 - 80 000
+// steps, dataSet/input_*.params; loop SerialCode/d2q9-bgk.c:166-170), where a launch per pass costs a kernel
+// boundary (~1.5-3 us) plus a reload of the lattice through L2 however little it computes.
+//
+// Geometry: workgroup b owns the band of rows [4b, 4b+4), the full width; thread x owns column x of the band: four
+// cells, kept as two PAIRS for the packed arithmetic -- the interior pair (rows 1, 2) and the edge pair (rows 0, 3).
+// 36 VGPRs of state per lane; a 1024 x 1024 lattice is 256 workgroups of 1024 threads, one per CU.
+//   streaming in y inside the band : register renaming (free)
+//   streaming in x                 : DPP wave_shr / wave_shl; lane 0 / 63 of a wave take the neighbouring wave's edge
+//                                    lane from LDS (one s_barrier per timestep, two LDS slots by parity)
+//   rows 0 and 3 also need the adjacent row of the neighbouring BAND: the 3 populations that cross the seam travel
+//   through L2 as 8-byte {value, tag} granules -- one sc1 (write-through, L1-bypassing) store per value, the tag is
+//   the global timestep index + 1, so the data is its own flag: no fence, no separate flag, no device-wide barrier.
+//   Two slots by step parity: a slot is overwritten two steps later, by which time the neighbour has provably read
+//   it (it cannot have published the step in between otherwise).  The consumer loads granule x, x-1 or x+1, so the
+//   x-shift of the diagonal populations costs nothing on either side.
+// Per timestep: publish the edge rows (computed last in the previous step) -> LDS edge lanes -> barrier -> relax the
+// interior pair (hides the hop) -> poll the six halo granules -> relax the edge pair.  No redundant work at all.
+// Every spin is bounded (wall clock): on expiry the workgroup raises *status and leaves; every other workgroup
+// sees the status in its own spin and leaves too.  An error, never a hang.  The grid must be co-resident (host:
+// one workgroup per CU at most as many as the device has CUs).
+// Arithmetic: relax_pair_core + the per-cell exception path, i.e. the lattice stays bit-identical to the oracle;
+// |u| from the pre-collision moments as in the stream kernels.
+// ---------------------------------------------------------------------------------------------
+struct ResidentArgs {
+  const float* src;           // lattice to start from (row 0 of the slab)
+  float* dst;                 // lattice to leave the result in (may equal src)
+  const unsigned char* mask;
+  long plane_stride;
+  long row_pitch;
+  int pitch;
+  int nx, ny;
+  int n_steps;                // timesteps this launch advances
+  int accel_row;              // global row of accelerate_flow (ny - 2)
+  int accel_last;             // also apply the acceleration of the step after this launch's last one
+  float omega, a1, a2;
+  unsigned long long* gran;   // seam granules: [2 directions][bands][2 slots][3 populations][nx]
+  unsigned epoch0;            // tag of this launch's step s = epoch0 + s + 1 (global step index + 1: never repeats)
+  float* partials;            // partials[s * bands + b] = sum |u| over band b after step s
+  int* status;                // 0, or kResidentTimeout once any workgroup gave up waiting
+  long long timeout_ticks;    // bound of one halo wait in wall_clock64() ticks (100 MHz)
+  int absent_band;            // tests: this band's workgroup returns at once, as if it had never been scheduled (-1: none)
+};
+constexpr int kResidentRows = 4;
+constexpr int kResidentTimeout = 1;
+
+// per-cell lid flags (bit 0: cell .x, bit 1: cell .y): the pair's two cells lie in different rows here
+__device__ __forceinline__ void relax_pair_fixup_rows(const f2 (&f)[kQ], bool ok, unsigned blocked, unsigned lid, float omega,
+                                                      float a1, float a2, f2 (&r)[kQ], float& sp0, float& sp1) {
+  if (!ok || blocked != 0 || lid != 0) {
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      const bool is_blocked = ((blocked >> (8 * c)) & 0xffu) != 0;
+      const bool is_lid = ((lid >> c) & 1u) != 0;
+      if (!ok || is_blocked || is_lid) {
+        float ts[kQ], rs[kQ], speed;
+#pragma unroll
+        for (int k = 0; k < kQ; k++) ts[k] = f[k][c];
+        relax_cell<0, 1>(ts, is_blocked, is_lid, omega, a1, a2, rs, speed, true);
+#pragma unroll
+        for (int k = 0; k < kQ; k++) r[k][c] = rs[k];
+        if (c == 0) sp0 = speed; else sp1 = speed;
+      }
+    }
+  }
+}
+__device__ __forceinline__ float relax_pair_rows(const f2 (&f)[kQ], unsigned blocked, unsigned lid, float omega, float a1,
+                                                 float a2, f2 (&r)[kQ]) {
+  f2 u_sq;
+  const bool ok = relax_pair_core(f, omega, r, u_sq);
+  float sp0 = __builtin_amdgcn_sqrtf(u_sq.x), sp1 = __builtin_amdgcn_sqrtf(u_sq.y);
+  relax_pair_fixup_rows(f, ok, blocked, lid, omega, a1, a2, r, sp0, sp1);
+  return sp0 + sp1;
+}
+
+// lane i <- lane i-1 (i+1); the wave's first (last) lane, which has no such lane, keeps `edge`
+__device__ __forceinline__ float shift_from_west(float v, float edge) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float shift_from_east(float v, float edge) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+// sum over the wave by DPP (no LDS); valid in lane 63
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));  // row_bcast:15 into rows 1 and 3
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
+typedef unsigned long long granule_t;
+__device__ __forceinline__ void granule_store(granule_t* p, float value, unsigned tag) {
+  __hip_atomic_store(p, ((granule_t)tag << 32) | (granule_t)__float_as_uint(value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
+  const int x = threadIdx.x, lane = x & 63, wave = x >> 6, n_waves = blockDim.x >> 6;
+  const int b = blockIdx.x, bands = gridDim.x;
+  const long ps = a.plane_stride;
+  // wave-edge values: [parity][wave][side: 0 = lane 0's west-moving, 1 = lane 63's east-moving][10 used of 12]
+  __shared__ __attribute__((aligned(16))) float edge[2][MAXT / 64][2][12];
+  __shared__ float wave_part[2][MAXT / 64];
+  if (b == a.absent_band) return;
+
+  // ---- the band's four rows: interior pair = rows (1, 2), edge pair = rows (0, 3) ----------------------------
+  f2 ri[kQ], re[kQ];
+  {
+    const float* base = a.src + (long)(kResidentRows * b) * a.row_pitch + x;
+#pragma unroll
+    for (int k = 0; k < kQ; k++) {
+      ri[k] = f2{base[1 * a.row_pitch + k * ps], base[2 * a.row_pitch + k * ps]};
+      re[k] = f2{base[k * ps], base[3 * a.row_pitch + k * ps]};
+    }
+  }
+  const unsigned char* mp = a.mask + (long)(kResidentRows * b) * a.pitch + x;
+  const unsigned blocked_i = (unsigned)mp[a.pitch] | ((unsigned)mp[2 * a.pitch] << 8);
+  const unsigned blocked_e = (unsigned)mp[0] | ((unsigned)mp[3 * a.pitch] << 8);
+  // accelerate_flow's row, if this band holds it: bit per cell of the pair it falls in
+  const int lid_local = a.accel_row - kResidentRows * b;
+  const unsigned lid_i = (lid_local == 1) ? 1u : (lid_local == 2 ? 2u : 0u);
+  const unsigned lid_e = (lid_local == 0) ? 1u : (lid_local == 3 ? 2u : 0u);
+
+  // seam granules: `up` carries a band's row-3 populations 2,5,6 northwards, `down` its row-0 populations 4,7,8
+  const long per_band = 2L * 3 * a.nx;
+  granule_t* up = a.gran;
+  granule_t* down = a.gran + (long)bands * per_band;
+  const int bs = (b == 0) ? bands - 1 : b - 1, bn = (b == bands - 1) ? 0 : b + 1;
+  const int xw = (x == 0) ? a.nx - 1 : x - 1, xe = (x == a.nx - 1) ? 0 : x + 1;
+  granule_t* my_up = up + (long)b * per_band + x;
+  granule_t* my_down = down + (long)b * per_band + x;
+  const granule_t* from_south = up + (long)bs * per_band;
+  const granule_t* from_north = down + (long)bn * per_band;
+  const int west_wave = (wave == 0) ? n_waves - 1 : wave - 1, east_wave = (wave == n_waves - 1) ? 0 : wave + 1;
+
+  bool alive = true;
+  for (int s = 0; s < a.n_steps && alive; s++) {
+    const unsigned tag = a.epoch0 + (unsigned)s + 1u;
+    const int slot = s & 1;
+    // ---- publish the edge rows of the current state -------------------------------------------------------
+    {
+      granule_t* u = my_up + (long)slot * 3 * a.nx;
+      granule_t* d = my_down + (long)slot * 3 * a.nx;
+      granule_store(u, re[2].y, tag);  granule_store(u + a.nx, re[5].y, tag);  granule_store(u + 2 * a.nx, re[6].y, tag);
+      granule_store(d, re[4].x, tag);  granule_store(d + a.nx, re[7].x, tag);  granule_store(d + 2 * a.nx, re[8].x, tag);
+    }
+    // ---- wave-edge lanes through LDS ------------------------------------------------------------------------
+    // east-moving (from lane 63): 1 of rows 0..3, 5 of rows 0..2, 8 of rows 1..3; west-moving (from lane 0): 3, 6, 7
+    if (lane == 63) {
+      float* e = edge[slot][wave][1];
+      e[0] = re[1].x; e[1] = ri[1].x; e[2] = ri[1].y; e[3] = re[1].y;
+      e[4] = re[5].x; e[5] = ri[5].x; e[6] = ri[5].y; e[7] = ri[8].x;
+      e[8] = ri[8].y; e[9] = re[8].y;
+    }
+    if (lane == 0) {
+      float* e = edge[slot][wave][0];
+      e[0] = re[3].x; e[1] = ri[3].x; e[2] = ri[3].y; e[3] = re[3].y;
+      e[4] = re[6].x; e[5] = ri[6].x; e[6] = ri[6].y; e[7] = ri[7].x;
+      e[8] = ri[7].y; e[9] = re[7].y;
+    }
+    __syncthreads();
+    if (s > 0 && wave == 0) {
+      // the per-wave sums of the previous step, written before this barrier: one partial per band and step
+      float v = (lane < n_waves) ? wave_part[slot ^ 1][lane] : 0.f;
+      for (int off = 8; off > 0; off >>= 1) v += __shfl_down(v, off, 16);
+      if (lane == 0) a.partials[(long)(s - 1) * bands + b] = v;
+    }
+    float W[10], E[10];
+    {
+      const float* w = edge[slot][west_wave][1];
+      const float* e = edge[slot][east_wave][0];
+#pragma unroll
+      for (int j = 0; j < 10; j++) { W[j] = w[j]; E[j] = e[j]; }
+    }
+    // shifted populations (the value each cell receives from its west / east neighbour), by source row
+    const float s1_0 = shift_from_west(re[1].x, W[0]), s1_1 = shift_from_west(ri[1].x, W[1]);
+    const float s1_2 = shift_from_west(ri[1].y, W[2]), s1_3 = shift_from_west(re[1].y, W[3]);
+    const float s5_0 = shift_from_west(re[5].x, W[4]), s5_1 = shift_from_west(ri[5].x, W[5]), s5_2 = shift_from_west(ri[5].y, W[6]);
+    const float s8_1 = shift_from_west(ri[8].x, W[7]), s8_2 = shift_from_west(ri[8].y, W[8]), s8_3 = shift_from_west(re[8].y, W[9]);
+    const float s3_0 = shift_from_east(re[3].x, E[0]), s3_1 = shift_from_east(ri[3].x, E[1]);
+    const float s3_2 = shift_from_east(ri[3].y, E[2]), s3_3 = shift_from_east(re[3].y, E[3]);
+    const float s6_0 = shift_from_east(re[6].x, E[4]), s6_1 = shift_from_east(ri[6].x, E[5]), s6_2 = shift_from_east(ri[6].y, E[6]);
+    const float s7_1 = shift_from_east(ri[7].x, E[7]), s7_2 = shift_from_east(ri[7].y, E[8]), s7_3 = shift_from_east(re[7].y, E[9]);
+
+    // ---- interior pair: rows 1 and 2 pull from rows 0..3 of the band only -------------------------------------
+    const bool accel = (s + 1 < a.n_steps) || a.accel_last;
+    f2 ti[kQ] = {ri[0], f2{s1_1, s1_2}, f2{re[2].x, ri[2].x}, f2{s3_1, s3_2}, f2{ri[4].y, re[4].y},
+                 f2{s5_0, s5_1}, f2{s6_0, s6_1}, f2{s7_2, s7_3}, f2{s8_2, s8_3}};
+    // what rows 0 and 3 pull from inside the band (kept before the interior pair is overwritten)
+    const float t4_0 = ri[4].x, t2_3 = ri[2].y;
+    f2 ni[kQ];
+    float sum = relax_pair_rows(ti, blocked_i, accel ? lid_i : 0u, a.omega, a.a1, a.a2, ni);
+
+    // ---- edge pair: rows 0 and 3 also pull from the neighbouring bands ----------------------------------------
+    float h2, h5, h6, h4, h7, h8;
+    {
+      const granule_t* gs = from_south + (long)slot * 3 * a.nx;
+      const granule_t* gn = from_north + (long)slot * 3 * a.nx;
+      long long t_start = 0;
+      for (unsigned spins = 0;; spins++) {
+        const granule_t g2 = __hip_atomic_load(gs + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const granule_t g5 = __hip_atomic_load(gs + a.nx + xw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const granule_t g6 = __hip_atomic_load(gs + 2 * a.nx + xe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const granule_t g4 = __hip_atomic_load(gn + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const granule_t g7 = __hip_atomic_load(gn + a.nx + xe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const granule_t g8 = __hip_atomic_load(gn + 2 * a.nx + xw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool ok = ((unsigned)(g2 >> 32) == tag) & ((unsigned)(g5 >> 32) == tag) & ((unsigned)(g6 >> 32) == tag) &
+                        ((unsigned)(g4 >> 32) == tag) & ((unsigned)(g7 >> 32) == tag) & ((unsigned)(g8 >> 32) == tag);
+        h2 = __uint_as_float((unsigned)g2);  h5 = __uint_as_float((unsigned)g5);  h6 = __uint_as_float((unsigned)g6);
+        h4 = __uint_as_float((unsigned)g4);  h7 = __uint_as_float((unsigned)g7);  h8 = __uint_as_float((unsigned)g8);
+        if (__all(ok)) break;
+        // not there yet: every so often look at the clock and at what the other workgroups say (wave-uniform)
+        if ((spins & 63u) == 63u) {
+          const long long now = wall_clock64();
+          if (t_start == 0) t_start = now;
+          const int st = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (st != 0 || now - t_start > a.timeout_ticks) {
+            if (st == 0 && lane == 0) __hip_atomic_store(a.status, kResidentTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            alive = false;
+            break;
+          }
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    f2 te[kQ] = {re[0], f2{s1_0, s1_3}, f2{h2, t2_3}, f2{s3_0, s3_3}, f2{t4_0, h4},
+                 f2{h5, s5_2}, f2{h6, s6_2}, f2{s7_1, h7}, f2{s8_1, h8}};
+    f2 ne[kQ];
+    sum += relax_pair_rows(te, blocked_e, accel ? lid_e : 0u, a.omega, a.a1, a.a2, ne);
+#pragma unroll
+    for (int k = 0; k < kQ; k++) { ri[k] = ni[k]; re[k] = ne[k]; }
+    // blocked cells report 0; sum over the wave, one partial per wave into LDS (summed after the next barrier)
+    const float tot = wave_sum_dpp(sum);
+    if (lane == 63) wave_part[slot][wave] = tot;
+    // (a wave that gave up leaves the loop alone: the hardware barrier counts only waves that have not ended, and
+    // the others find *status set in their next spin)
+  }
+
+  __syncthreads();
+  if (a.n_steps > 0 && wave == 0) {
+    float v = (lane < n_waves) ? wave_part[(a.n_steps - 1) & 1][lane] : 0.f;
+    for (int off = 8; off > 0; off >>= 1) v += __shfl_down(v, off, 16);
+    if (lane == 0) a.partials[(long)(a.n_steps - 1) * bands + b] = v;
+  }
+  float* out = a.dst + (long)(kResidentRows * b) * a.row_pitch + x;
+#pragma unroll
+  for (int k = 0; k < kQ; k++) {
+    out[k * ps] = re[k].x;
+    out[1 * a.row_pitch + k * ps] = ri[k].x;
+    out[2 * a.row_pitch + k * ps] = ri[k].y;
+    out[3 * a.row_pitch + k * ps] = re[k].y;
+  }
+}
+
+// resident kernel: sum the per-band partials of each step in a fixed order (double) -> tot_u[step_base + s]
+__global__ __launch_bounds__(64) void reduce_band_partials(const float* partials, int bands, double* tot_u, int step_base) {
+  const float* p = partials + (long)blockIdx.x * bands;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < bands; i += 64) acc += (double)p[i];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (threadIdx.x == 0) tot_u[step_base + blockIdx.x] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
 // fused step, 1 cell per lane: any nx (fallback for widths that are not a multiple of 4)
 // ---------------------------------------------------------------------------------------------
 template <bool EXACT>
