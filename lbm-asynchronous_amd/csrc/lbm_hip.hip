@@ -166,7 +166,7 @@ struct Slab {
   double* scratch = nullptr;  // 2 x kSumBlocks doubles for lattice_sums
   double* reduce_buf = nullptr;  // ranked contexts: capacity doubles for the av_vels all-reduce
   int* flushed_dev = nullptr; // graph replay: index of the first step of the chunk being reduced
-  unsigned long long* res_gran = nullptr;  // resident kernel: seam granules [2][bands][2][3][nx]
+  uint4* res_gran = nullptr;               // resident kernel: seam granules {v, v, v, tag}: [2][bands][2][nx]
   float* res_part = nullptr;               // resident kernel: per-band partial sums of a launch, [kResidentChunk][bands]
   int* res_status = nullptr;               // resident kernel: 0, or the reason a workgroup gave up
   hipGraphExec_t chunk_graph[2] = {nullptr, nullptr};  // kPartSlots timesteps + their reduce, by lattice parity
@@ -1111,6 +1111,7 @@ int run_resident(lbm_ctx* c, int n_steps) {
     a.a1 = c->p.density * c->p.accel / 9.f;
     a.a2 = c->p.density * c->p.accel / 36.f;
     a.gran = sl.res_gran;
+    a.gran_bytes = (unsigned)(2UL * c->resident_bands * 2 * c->p.nx * sizeof(uint4));
     a.epoch0 = (unsigned)(c->steps_done + t);
     a.partials = sl.res_part;
     a.status = sl.res_status;
@@ -1357,7 +1358,7 @@ int build_slab(lbm_ctx* c, int s, const ObstacleSource& obst, const float* cells
   HIP_TRY(LBM_FAILURE, hipMalloc(&sl.flushed_dev, sizeof(int)));
   if (c->resident) {
     // granules start at tag 0 = "nothing"; tags are global step indices + 1, so they never need clearing again
-    const size_t gran_bytes = 2UL * c->resident_bands * 2 * 3 * p.nx * sizeof(unsigned long long);
+    const size_t gran_bytes = 2UL * c->resident_bands * 2 * p.nx * sizeof(uint4);
     HIP_TRY(LBM_FAILURE, hipMalloc(&sl.res_gran, gran_bytes));
     HIP_TRY(LBM_FAILURE, hipMemsetAsync(sl.res_gran, 0, gran_bytes, sl.compute));
     HIP_TRY(LBM_FAILURE, hipMalloc(&sl.res_part, (size_t)kResidentChunk * c->resident_bands * sizeof(float)));

@@ -1429,11 +1429,14 @@ __global__ __launch_bounds__(THREADS) void step_tile(const TileArgs a) {
 //   streaming in x                 : DPP wave_shr / wave_shl; lane 0 / 63 of a wave take the neighbouring wave's edge
 //                                    lane from LDS (one s_barrier per timestep, two LDS slots by parity)
 //   rows 0 and 3 also need the adjacent row of the neighbouring BAND: the 3 populations that cross the seam travel
-//   through L2 as 8-byte {value, tag} granules -- one sc1 (write-through, L1-bypassing) store per value, the tag is
-//   the global timestep index + 1, so the data is its own flag: no fence, no separate flag, no device-wide barrier.
+//   through L2 as one 16-byte granule per cell and direction, {v, v, v, tag} -- ONE sc1 (write-through, L1-bypassing)
+//   dwordx4 store, naturally aligned, so it lies inside one 64-byte memory request on the way out and on the way in;
+//   the tag is the global timestep index + 1, i.e. the data is its own flag: no fence, no separate flag, no
+//   device-wide barrier.  (8-byte {value, tag} granules, the form MI355X_MICROARCH.md prices, cost three narrow sc1
+//   stores per cell and direction: 12.6 MB per step at 1024^2, store-bound at 5.9 us per step.)
 //   Two slots by step parity: a slot is overwritten two steps later, by which time the neighbour has provably read
-//   it (it cannot have published the step in between otherwise).  The consumer loads granule x, x-1 or x+1, so the
-//   x-shift of the diagonal populations costs nothing on either side.
+//   it (it cannot have published the step in between otherwise).  A lane loads the granule of its own column; the
+//   diagonal populations shift by DPP, the wave's first / last lane taking the column beyond from a second load.
 // Per timestep: publish the edge rows (computed last in the previous step) -> LDS edge lanes -> barrier -> relax the
 // interior pair (hides the hop) -> poll the six halo granules -> relax the edge pair.  No redundant work at all.
 // Every spin is bounded (wall clock): on expiry the workgroup raises *status and leaves; every other workgroup
@@ -1454,7 +1457,8 @@ struct ResidentArgs {
   int accel_row;              // global row of accelerate_flow (ny - 2)
   int accel_last;             // also apply the acceleration of the step after this launch's last one
   float omega, a1, a2;
-  unsigned long long* gran;   // seam granules: [2 directions][bands][2 slots][3 populations][nx]
+  uint4* gran;                // seam granules {v, v, v, tag}: [2 directions][bands][2 slots][nx]
+  unsigned gran_bytes;        // size of the granule buffer
   unsigned epoch0;            // tag of this launch's step s = epoch0 + s + 1 (global step index + 1: never repeats)
   float* partials;            // partials[s * bands + b] = sum |u| over band b after step s
   int* status;                // 0, or kResidentTimeout once any workgroup gave up waiting
@@ -1512,9 +1516,18 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
   return v;
 }
 
-typedef unsigned long long granule_t;
-__device__ __forceinline__ void granule_store(granule_t* p, float value, unsigned tag) {
-  __hip_atomic_store(p, ((granule_t)tag << 32) | (granule_t)__float_as_uint(value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// 16-byte seam granule: three populations and the tag in ONE naturally aligned dwordx4 access with sc1 (agent scope:
+// the store writes through the XCD's L2, the load bypasses L1 and refetches), i.e. the raw-buffer forms with aux = sc1
+typedef int granule_vec __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t granule_rsrc(uint4* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void granule_store(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, float a, float b, float c, unsigned tag) {
+  const granule_vec v = {(int)__float_as_uint(a), (int)__float_as_uint(b), (int)__float_as_uint(c), (int)tag};
+  __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)byte_off, 0, 16);  // aux 16 = sc1
+}
+__device__ __forceinline__ granule_vec granule_load(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 16);
 }
 
 template <int MAXT>
@@ -1545,16 +1558,16 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
   const unsigned lid_i = (lid_local == 1) ? 1u : (lid_local == 2 ? 2u : 0u);
   const unsigned lid_e = (lid_local == 0) ? 1u : (lid_local == 3 ? 2u : 0u);
 
-  // seam granules: `up` carries a band's row-3 populations 2,5,6 northwards, `down` its row-0 populations 4,7,8
-  const long per_band = 2L * 3 * a.nx;
-  granule_t* up = a.gran;
-  granule_t* down = a.gran + (long)bands * per_band;
+  // seam granules: `up` carries a band's row-3 populations 2,5,6 northwards, `down` its row-0 populations 4,7,8;
+  // byte offsets into the one buffer (32-bit: it is at most 16 MiB)
+  const __amdgpu_buffer_rsrc_t grsrc = granule_rsrc(a.gran, a.gran_bytes);
+  const unsigned band_bytes = 2u * (unsigned)a.nx * 16u, slot_bytes = (unsigned)a.nx * 16u;
+  const unsigned down_base = (unsigned)bands * band_bytes;
   const int bs = (b == 0) ? bands - 1 : b - 1, bn = (b == bands - 1) ? 0 : b + 1;
   const int xw = (x == 0) ? a.nx - 1 : x - 1, xe = (x == a.nx - 1) ? 0 : x + 1;
-  granule_t* my_up = up + (long)b * per_band + x;
-  granule_t* my_down = down + (long)b * per_band + x;
-  const granule_t* from_south = up + (long)bs * per_band;
-  const granule_t* from_north = down + (long)bn * per_band;
+  const unsigned my_up = (unsigned)b * band_bytes + (unsigned)x * 16u;
+  const unsigned my_down = down_base + (unsigned)b * band_bytes + (unsigned)x * 16u;
+  const unsigned from_south = (unsigned)bs * band_bytes, from_north = down_base + (unsigned)bn * band_bytes;
   const int west_wave = (wave == 0) ? n_waves - 1 : wave - 1, east_wave = (wave == n_waves - 1) ? 0 : wave + 1;
 
   bool alive = true;
@@ -1562,12 +1575,8 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
     const unsigned tag = a.epoch0 + (unsigned)s + 1u;
     const int slot = s & 1;
     // ---- publish the edge rows of the current state -------------------------------------------------------
-    {
-      granule_t* u = my_up + (long)slot * 3 * a.nx;
-      granule_t* d = my_down + (long)slot * 3 * a.nx;
-      granule_store(u, re[2].y, tag);  granule_store(u + a.nx, re[5].y, tag);  granule_store(u + 2 * a.nx, re[6].y, tag);
-      granule_store(d, re[4].x, tag);  granule_store(d + a.nx, re[7].x, tag);  granule_store(d + 2 * a.nx, re[8].x, tag);
-    }
+    granule_store(grsrc, my_up + (unsigned)slot * slot_bytes, re[2].y, re[5].y, re[6].y, tag);
+    granule_store(grsrc, my_down + (unsigned)slot * slot_bytes, re[4].x, re[7].x, re[8].x, tag);
     // ---- wave-edge lanes through LDS ------------------------------------------------------------------------
     // east-moving (from lane 63): 1 of rows 0..3, 5 of rows 0..2, 8 of rows 1..3; west-moving (from lane 0): 3, 6, 7
     if (lane == 63) {
@@ -1618,20 +1627,27 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
     // ---- edge pair: rows 0 and 3 also pull from the neighbouring bands ----------------------------------------
     float h2, h5, h6, h4, h7, h8;
     {
-      const granule_t* gs = from_south + (long)slot * 3 * a.nx;
-      const granule_t* gn = from_north + (long)slot * 3 * a.nx;
+      const unsigned gs = from_south + (unsigned)slot * slot_bytes, gn = from_north + (unsigned)slot * slot_bytes;
+      // the wave's first lane also needs the column west of it, its last lane the column east of it
+      const bool first = (lane == 0), last = (lane == 63);
+      // (every lane issues the second load, the inner lanes for their own column again: four loads in flight, one
+      // wait, no divergent branch in the spin)
+      const unsigned x_side = (unsigned)(first ? xw : (last ? xe : x)) * 16u;
       long long t_start = 0;
       for (unsigned spins = 0;; spins++) {
-        const granule_t g2 = __hip_atomic_load(gs + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const granule_t g5 = __hip_atomic_load(gs + a.nx + xw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const granule_t g6 = __hip_atomic_load(gs + 2 * a.nx + xe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const granule_t g4 = __hip_atomic_load(gn + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const granule_t g7 = __hip_atomic_load(gn + a.nx + xe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const granule_t g8 = __hip_atomic_load(gn + 2 * a.nx + xw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool ok = ((unsigned)(g2 >> 32) == tag) & ((unsigned)(g5 >> 32) == tag) & ((unsigned)(g6 >> 32) == tag) &
-                        ((unsigned)(g4 >> 32) == tag) & ((unsigned)(g7 >> 32) == tag) & ((unsigned)(g8 >> 32) == tag);
-        h2 = __uint_as_float((unsigned)g2);  h5 = __uint_as_float((unsigned)g5);  h6 = __uint_as_float((unsigned)g6);
-        h4 = __uint_as_float((unsigned)g4);  h7 = __uint_as_float((unsigned)g7);  h8 = __uint_as_float((unsigned)g8);
+        const granule_vec cs = granule_load(grsrc, gs + (unsigned)x * 16u);
+        const granule_vec cn = granule_load(grsrc, gn + (unsigned)x * 16u);
+        const granule_vec ss = granule_load(grsrc, gs + x_side);
+        const granule_vec sn = granule_load(grsrc, gn + x_side);
+        const bool ok = ((unsigned)cs.w == tag) & ((unsigned)cn.w == tag) & ((unsigned)ss.w == tag) & ((unsigned)sn.w == tag);
+        // south: {2, 5, 6} of its row 3; north: {4, 7, 8} of its row 0; 5 and 8 come from the west column, 6 and 7 from the east
+        const float side_s = __uint_as_float((unsigned)(first ? ss.y : ss.z)), side_n = __uint_as_float((unsigned)(first ? sn.z : sn.y));
+        h2 = __uint_as_float((unsigned)cs.x);
+        h4 = __uint_as_float((unsigned)cn.x);
+        h5 = shift_from_west(__uint_as_float((unsigned)cs.y), side_s);
+        h6 = shift_from_east(__uint_as_float((unsigned)cs.z), side_s);
+        h7 = shift_from_east(__uint_as_float((unsigned)cn.y), side_n);
+        h8 = shift_from_west(__uint_as_float((unsigned)cn.z), side_n);
         if (__all(ok)) break;
         // not there yet: every so often look at the clock and at what the other workgroups say (wave-uniform)
         if ((spins & 63u) == 63u) {
