@@ -183,13 +183,21 @@ def cpu_baseline_multicore(nx, ny, threads=16, budget_s=6.0):
     return None
 
 
-def pmc_record(nx, ny, math, info):
+def runs_resident(info, steps):
+    """True when an lbm_run call of `steps` timesteps on this engine is served by the resident kernel."""
+    return info.get("resident_steps", 0) > 0 and steps >= info.get("resident_min_steps", 1)
+
+
+def pmc_record(nx, ny, math, info, steps=0):
     """Committed rocprofv3 --pmc figures for EXACTLY this kernel geometry (profiles/pmc_traffic.json, collected as
     MI355X_MICROARCH.md prescribes: separate passes, FETCH_SIZE x2 on gfx950), or None.  Not a measurement of this
     run: the record names the commit and the run it came from, and is dropped when grid, math, timesteps per
     launch, band height or cells per lane differ from what is running."""
-    key = (f"{nx}x{ny}/math={math}/steps_per_launch={info['steps_per_launch']}"
-           f"/band={info['band_rows']}/lane_cells={info['lane_cells']}")
+    if runs_resident(info, steps):
+        key = f"{nx}x{ny}/resident"         # lbm::resident_band: one geometry per grid, the same arithmetic in both math modes
+    else:
+        key = (f"{nx}x{ny}/math={math}/steps_per_launch={info['steps_per_launch']}"
+               f"/band={info['band_rows']}/lane_cells={info['lane_cells']}")
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             rec = json.load(fh).get(key)
@@ -340,8 +348,11 @@ def main():
         compulsory_bytes = BYTES_PER_UPDATE * nx * rows_per_rank
         launch_ms = kernel_ms * spl
         achieved = compulsory_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-        pmc = pmc_record(nx, ny, args.math, info) if world == 1 else None
-        if info["lane_cells"] > 0:      # a stream kernel: several timesteps per pass
+        pmc = pmc_record(nx, ny, args.math, info, args.steps) if world == 1 else None
+        if runs_resident(info, args.steps):
+            kernel_name = "lbm::resident_band"
+            spl = args.steps            # one launch advances the whole timed region
+        elif info["lane_cells"] > 0:      # a stream kernel: several timesteps per pass
             kernel_name = ("lbm::stepk_pk" if args.math == "exact" else
                            ("lbm::stepk_stream" if info["lane_cells"] == 4 else "lbm::step2_stream"))
         else:
@@ -572,7 +583,11 @@ def main():
                                       "warmup": wu, "repeats": 3, "steps_per_launch": inf["steps_per_launch"],
                                       "band_rows": inf["band_rows"], "lane_cells": inf["lane_cells"],
                                       "results_finite": fin, "note": note}
-                rec = pmc_record(gx, gy, args.math, inf) if world == 1 else None
+                if runs_resident(inf, st):
+                    also[f"{gx}x{gy}"].update(kernel="lbm::resident_band", steps_per_launch=min(st, inf["resident_steps"]),
+                                              kernel_note="one launch per lbm_run call: the lattice stays in registers, 4-row bands "
+                                                          "per workgroup, seam rows through tagged L2 granules")
+                rec = pmc_record(gx, gy, args.math, inf, st) if world == 1 else None
                 if rec:     # committed PMC profile of exactly this kernel geometry (not measured in this run)
                     also[f"{gx}x{gy}"]["limiter"] = {"valu_busy": rec.get("valu_busy"), "issue_busy": rec.get("issue_busy"),
                                                      "lane_instructions_per_update": rec.get("lane_instructions_per_update"),

@@ -169,6 +169,7 @@ struct Slab {
   uint4* res_gran = nullptr;               // resident kernel: seam granules {v, v, v, tag}: [2][bands][2][nx]
   float* res_part = nullptr;               // resident kernel: per-band partial sums of a launch, [kResidentChunk][bands]
   int* res_status = nullptr;               // resident kernel: 0, or the reason a workgroup gave up
+  int* res_status_host = nullptr;          // pinned copy of it, refreshed behind every launch (read by lbm_sync)
   hipGraphExec_t chunk_graph[2] = {nullptr, nullptr};  // kPartSlots timesteps + their reduce, by lattice parity
   hipStream_t compute = nullptr, comm = nullptr;
   hipEvent_t ev_boundary = nullptr, ev_halo = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
@@ -354,6 +355,7 @@ struct lbm_ctx {
   int resident = 0;                 // single periodic slab that fits the chip's registers: lbm_run calls of at least
   int resident_min_steps = 16;      // ... this many timesteps run as launches of the resident kernel (lbm::resident_band)
   int resident_bands = 0;           // its workgroups (bands of kResidentRows rows)
+  int resident_joint = 0;           // narrow grids: both pairs of a lane relaxed as one block behind the halo wait
   long long resident_timeout = 0;   // bound of one halo wait, wall-clock ticks
   bool resident_used = false;       // a launch is in flight / unchecked: lbm_sync reads its status
   int tile_steps = 0;               // > 0: single slab advanced by the LDS-tile kernel, this many steps per launch
@@ -1111,7 +1113,8 @@ int run_resident(lbm_ctx* c, int n_steps) {
     a.a1 = c->p.density * c->p.accel / 9.f;
     a.a2 = c->p.density * c->p.accel / 36.f;
     a.gran = sl.res_gran;
-    a.gran_bytes = (unsigned)(2UL * c->resident_bands * 2 * c->p.nx * sizeof(uint4));
+    a.gran_bytes = (unsigned)((2UL * c->resident_bands * 2 * c->p.nx + c->resident_bands) * sizeof(uint4));
+    a.xcd_affinity = env_int("LBM_RESIDENT_XCD", 1) ? 1 : 0;
     a.epoch0 = (unsigned)(c->steps_done + t);
     a.partials = sl.res_part;
     a.status = sl.res_status;
@@ -1119,7 +1122,8 @@ int run_resident(lbm_ctx* c, int n_steps) {
     a.absent_band = env_int("LBM_RESIDENT_ABSENT_BAND", -1);  // tests of the give-up path
     void* args[] = {&a};
     const void* fn = (c->p.nx > 512) ? reinterpret_cast<const void*>(lbm::resident_band<1024>)
-                                     : reinterpret_cast<const void*>(lbm::resident_band<512>);
+                     : (c->resident_joint ? reinterpret_cast<const void*>(lbm::resident_band<512, true>)
+                                          : reinterpret_cast<const void*>(lbm::resident_band<512>));
     HIP_TRY(LBM_FAILURE, hipLaunchKernel(fn, dim3(c->resident_bands), dim3(c->p.nx), args, 0, sl.compute));
     hipLaunchKernelGGL(lbm::reduce_band_partials, dim3(n), dim3(64), 0, sl.compute, (const float*)sl.res_part,
                        c->resident_bands, sl.tot_u, c->steps_done + t);
@@ -1127,6 +1131,8 @@ int run_resident(lbm_ctx* c, int n_steps) {
     c->cur ^= 1;
     t += n;
   }
+  // the verdict of these launches travels to the host behind them; lbm_sync looks at it
+  HIP_TRY(LBM_FAILURE, hipMemcpyAsync(sl.res_status_host, sl.res_status, sizeof(int), hipMemcpyDeviceToHost, sl.compute));
   c->resident_used = true;
   return LBM_SUCCESS;
 }
@@ -1305,6 +1311,7 @@ void free_slab(Slab& sl) {
   if (sl.res_gran) (void)hipFree(sl.res_gran);
   if (sl.res_part) (void)hipFree(sl.res_part);
   if (sl.res_status) (void)hipFree(sl.res_status);
+  if (sl.res_status_host) (void)hipHostFree(sl.res_status_host);
   if (sl.ev_boundary) (void)hipEventDestroy(sl.ev_boundary);
   if (sl.ev_halo) (void)hipEventDestroy(sl.ev_halo);
   for (int i = 0; i < 2; i++) if (sl.ev_interior[i]) (void)hipEventDestroy(sl.ev_interior[i]);
@@ -1358,12 +1365,14 @@ int build_slab(lbm_ctx* c, int s, const ObstacleSource& obst, const float* cells
   HIP_TRY(LBM_FAILURE, hipMalloc(&sl.flushed_dev, sizeof(int)));
   if (c->resident) {
     // granules start at tag 0 = "nothing"; tags are global step indices + 1, so they never need clearing again
-    const size_t gran_bytes = 2UL * c->resident_bands * 2 * p.nx * sizeof(uint4);
+    const size_t gran_bytes = (2UL * c->resident_bands * 2 * p.nx + c->resident_bands) * sizeof(uint4);  // + one XCC-id granule per band
     HIP_TRY(LBM_FAILURE, hipMalloc(&sl.res_gran, gran_bytes));
     HIP_TRY(LBM_FAILURE, hipMemsetAsync(sl.res_gran, 0, gran_bytes, sl.compute));
     HIP_TRY(LBM_FAILURE, hipMalloc(&sl.res_part, (size_t)kResidentChunk * c->resident_bands * sizeof(float)));
     HIP_TRY(LBM_FAILURE, hipMalloc(&sl.res_status, sizeof(int)));
     HIP_TRY(LBM_FAILURE, hipMemsetAsync(sl.res_status, 0, sizeof(int), sl.compute));
+    HIP_TRY(LBM_FAILURE, hipHostMalloc(&sl.res_status_host, sizeof(int)));
+    *sl.res_status_host = 0;
   }
   if (c->ranked) HIP_TRY(LBM_FAILURE, hipMalloc(&sl.reduce_buf, (size_t)(c->capacity > 0 ? c->capacity : 1) * sizeof(double)));
 
@@ -1754,7 +1763,12 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
           ny / lbm::kResidentRows <= cus) {
         c->resident = 1;
         c->resident_bands = ny / lbm::kResidentRows;
-        c->resident_min_steps = env_int("LBM_RESIDENT_MIN_STEPS", 16);
+        c->resident_joint = (nx <= 512 && env_int("LBM_RESIDENT_JOINT", nx <= 256 ? 1 : 0)) ? 1 : 0;
+        // a launch costs about 35 us before its first step (lattice into registers, back out, reduce); measured wall
+        // time of one lbm_run(n) + sync, per-pass kernels | resident: 128^2 n = 64 149 | 156, n = 128 285 | 277;
+        // 256^2 n = 16 66 | 69, n = 32 115 | 100; 1024^2 n = 4 63 | 63, n = 8 100 | 83 (tools/resident_crossover.py)
+        const long cells = (long)nx * ny;
+        c->resident_min_steps = env_int("LBM_RESIDENT_MIN_STEPS", cells >= 512L * 1024 ? 8 : (cells >= 48L * 1024 ? 32 : 128));
         if (c->resident_min_steps < 1) c->resident_min_steps = 1;
         c->resident_timeout = (long long)env_int("LBM_RESIDENT_TIMEOUT_MS", 2000) * 100000LL;  // wall_clock64(): 100 MHz
       }
@@ -2095,8 +2109,7 @@ int lbm_sync(lbm_ctx* c) {
   }
   if (c->resident_used) {
     // did every workgroup of the resident kernel get its neighbours' rows in time?
-    int status = 0;
-    HIP_TRY(LBM_FAILURE, hipMemcpy(&status, c->slab[0].res_status, sizeof(status), hipMemcpyDeviceToHost));
+    const int status = *c->slab[0].res_status_host;
     c->resident_used = false;
     if (status != 0)
       LBM_FAIL(LBM_FAILURE, "the resident kernel gave up waiting for a neighbouring band after %.0f ms (status %d): its %d workgroups "

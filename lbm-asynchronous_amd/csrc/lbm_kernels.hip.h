@@ -1463,6 +1463,7 @@ struct ResidentArgs {
   float* partials;            // partials[s * bands + b] = sum |u| over band b after step s
   int* status;                // 0, or kResidentTimeout once any workgroup gave up waiting
   long long timeout_ticks;    // bound of one halo wait in wall_clock64() ticks (100 MHz)
+  int xcd_affinity;           // 1: seams inside one XCD use L2-resident stores (see resident_band); 0: sc1 everywhere
   int absent_band;            // tests: this band's workgroup returns at once, as if it had never been scheduled (-1: none)
 };
 constexpr int kResidentRows = 4;
@@ -1497,6 +1498,28 @@ __device__ __forceinline__ float relax_pair_rows(const f2 (&f)[kQ], unsigned blo
   return sp0 + sp1;
 }
 
+// sum over the first 16 lanes (one DPP row), valid in every lane of that row
+__device__ __forceinline__ float row16_sum_dpp(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
+  return v;
+}
+
+// both pairs of a lane in one basic block (two independent dependency chains), the exceptions after both
+__device__ __forceinline__ float relax_two_pairs_rows(const f2 (&fa)[kQ], const f2 (&fb)[kQ], unsigned blocked_a, unsigned blocked_b,
+                                                      unsigned lid_a, unsigned lid_b, float omega, float a1, float a2,
+                                                      f2 (&ra)[kQ], f2 (&rb)[kQ]) {
+  f2 usq_a, usq_b;
+  const bool ok_a = relax_pair_core(fa, omega, ra, usq_a);
+  const bool ok_b = relax_pair_core(fb, omega, rb, usq_b);
+  float sp[4] = {__builtin_amdgcn_sqrtf(usq_a.x), __builtin_amdgcn_sqrtf(usq_a.y), __builtin_amdgcn_sqrtf(usq_b.x), __builtin_amdgcn_sqrtf(usq_b.y)};
+  relax_pair_fixup_rows(fa, ok_a, blocked_a, lid_a, omega, a1, a2, ra, sp[0], sp[1]);
+  relax_pair_fixup_rows(fb, ok_b, blocked_b, lid_b, omega, a1, a2, rb, sp[2], sp[3]);
+  return (sp[0] + sp[1]) + (sp[2] + sp[3]);
+}
+
 // lane i <- lane i-1 (i+1); the wave's first (last) lane, which has no such lane, keeps `edge`
 __device__ __forceinline__ float shift_from_west(float v, float edge) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
@@ -1526,14 +1549,29 @@ __device__ __forceinline__ void granule_store(__amdgpu_buffer_rsrc_t rsrc, unsig
   const granule_vec v = {(int)__float_as_uint(a), (int)__float_as_uint(b), (int)__float_as_uint(c), (int)tag};
   __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)byte_off, 0, 16);  // aux 16 = sc1
 }
+// the same store without sc1: the line stays (dirty) in this XCD's L2, where a reader on the SAME XCD finds it with
+// its sc1 (L1-bypassing) load at L2 latency instead of a round trip over the fabric
+__device__ __forceinline__ void granule_store_local(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, float a, float b, float c, unsigned tag) {
+  const granule_vec v = {(int)__float_as_uint(a), (int)__float_as_uint(b), (int)__float_as_uint(c), (int)tag};
+  __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)byte_off, 0, 0);
+}
 __device__ __forceinline__ granule_vec granule_load(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
   return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 16);
 }
 
-template <int MAXT>
+// JOINT: wait for the halo first and relax both pairs as ONE block of independent work -- for narrow grids, whose few
+// waves sit alone on their SIMDs: there the step is the dependent-instruction latency of the two collisions one after
+// the other, and two independent chains interleave (issue-bound instead of latency-bound).  Wide grids (four waves
+// per SIMD) keep the interior pair in front of the halo wait: their SIMDs are busy anyway and the interior pair
+// hides the hop.
+template <int MAXT, bool JOINT = false>
 __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
   const int x = threadIdx.x, lane = x & 63, wave = x >> 6, n_waves = blockDim.x >> 6;
-  const int b = blockIdx.x, bands = gridDim.x;
+  const int bands = gridDim.x;
+  // Workgroups are dealt to the 8 XCDs round-robin (observed, not promised): consecutive bands are given to
+  // workgroups 8 apart, so that most seams join two bands on ONE XCD.  Speed only -- which seams really do is
+  // established below from the hardware's own XCC id, and the protocol is correct for any placement.
+  const int b = (a.xcd_affinity && (bands & 7) == 0) ? (int)(blockIdx.x & 7) * (bands >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const long ps = a.plane_stride;
   // wave-edge values: [parity][wave][side: 0 = lane 0's west-moving, 1 = lane 63's east-moving][10 used of 12]
   __shared__ __attribute__((aligned(16))) float edge[2][MAXT / 64][2][12];
@@ -1568,6 +1606,37 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
   const unsigned my_up = (unsigned)b * band_bytes + (unsigned)x * 16u;
   const unsigned my_down = down_base + (unsigned)b * band_bytes + (unsigned)x * 16u;
   const unsigned from_south = (unsigned)bs * band_bytes, from_north = down_base + (unsigned)bn * band_bytes;
+  // which XCD do my neighbours run on?  Every band announces its XCC id in a granule of its own (sc1, tag = this
+  // launch's first epoch); a seam whose two bands share an XCD keeps its granules in that XCD's L2 (plain stores),
+  // any other seam writes them through (sc1).  The reader's loads are sc1 either way.
+  bool north_local = false, south_local = false;
+  if (a.xcd_affinity) {
+    const unsigned hello_base = 2u * down_base;
+    const unsigned my_xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;  // HW_REG_XCC_ID[3:0]
+    const unsigned hello_tag = a.epoch0 + 1u;
+    if (x == 0) granule_store(grsrc, hello_base + (unsigned)b * 16u, __uint_as_float(my_xcc), 0.f, 0.f, hello_tag);
+    long long t_start = 0;
+    for (unsigned spins = 0;; spins++) {
+      asm volatile("" ::: "memory");
+      const granule_vec hs = granule_load(grsrc, hello_base + (unsigned)bs * 16u);
+      const granule_vec hn = granule_load(grsrc, hello_base + (unsigned)bn * 16u);
+      if ((unsigned)hs.w == hello_tag && (unsigned)hn.w == hello_tag) {
+        south_local = ((unsigned)hs.x == my_xcc);
+        north_local = ((unsigned)hn.x == my_xcc);
+        break;
+      }
+      if ((spins & 63u) == 63u) {
+        const long long now = wall_clock64();
+        if (t_start == 0) t_start = now;
+        const int st = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (st != 0 || now - t_start > a.timeout_ticks) {
+          if (st == 0 && lane == 0) __hip_atomic_store(a.status, kResidentTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return;
+        }
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
   const int west_wave = (wave == 0) ? n_waves - 1 : wave - 1, east_wave = (wave == n_waves - 1) ? 0 : wave + 1;
 
   bool alive = true;
@@ -1575,8 +1644,10 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
     const unsigned tag = a.epoch0 + (unsigned)s + 1u;
     const int slot = s & 1;
     // ---- publish the edge rows of the current state -------------------------------------------------------
-    granule_store(grsrc, my_up + (unsigned)slot * slot_bytes, re[2].y, re[5].y, re[6].y, tag);
-    granule_store(grsrc, my_down + (unsigned)slot * slot_bytes, re[4].x, re[7].x, re[8].x, tag);
+    if (north_local) granule_store_local(grsrc, my_up + (unsigned)slot * slot_bytes, re[2].y, re[5].y, re[6].y, tag);
+    else granule_store(grsrc, my_up + (unsigned)slot * slot_bytes, re[2].y, re[5].y, re[6].y, tag);
+    if (south_local) granule_store_local(grsrc, my_down + (unsigned)slot * slot_bytes, re[4].x, re[7].x, re[8].x, tag);
+    else granule_store(grsrc, my_down + (unsigned)slot * slot_bytes, re[4].x, re[7].x, re[8].x, tag);
     // ---- wave-edge lanes through LDS ------------------------------------------------------------------------
     // east-moving (from lane 63): 1 of rows 0..3, 5 of rows 0..2, 8 of rows 1..3; west-moving (from lane 0): 3, 6, 7
     if (lane == 63) {
@@ -1594,8 +1665,7 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
     __syncthreads();
     if (s > 0 && wave == 0) {
       // the per-wave sums of the previous step, written before this barrier: one partial per band and step
-      float v = (lane < n_waves) ? wave_part[slot ^ 1][lane] : 0.f;
-      for (int off = 8; off > 0; off >>= 1) v += __shfl_down(v, off, 16);
+      const float v = row16_sum_dpp((lane < n_waves) ? wave_part[slot ^ 1][lane] : 0.f);
       if (lane == 0) a.partials[(long)(s - 1) * bands + b] = v;
     }
     float W[10], E[10];
@@ -1615,6 +1685,19 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
     const float s6_0 = shift_from_east(re[6].x, E[4]), s6_1 = shift_from_east(ri[6].x, E[5]), s6_2 = shift_from_east(ri[6].y, E[6]);
     const float s7_1 = shift_from_east(ri[7].x, E[7]), s7_2 = shift_from_east(ri[7].y, E[8]), s7_3 = shift_from_east(re[7].y, E[9]);
 
+    // ---- the halo granules are asked for NOW, before the interior pair is relaxed: when the neighbours are not late
+    // (the usual case: their edge rows were published about when ours were) the answer is there by the time the
+    // interior pair is done, and the round trip of the load is hidden behind it
+    const unsigned gs = from_south + (unsigned)slot * slot_bytes, gn = from_north + (unsigned)slot * slot_bytes;
+    // the wave's first lane also needs the column west of it, its last lane the column east of it (every lane issues
+    // the second load, the inner lanes for their own column again: four loads in flight, one wait, no divergence)
+    const bool first = (lane == 0), last = (lane == 63);
+    const unsigned x_side = (unsigned)(first ? xw : (last ? xe : x)) * 16u;
+    granule_vec cs = granule_load(grsrc, gs + (unsigned)x * 16u);
+    granule_vec cn = granule_load(grsrc, gn + (unsigned)x * 16u);
+    granule_vec ss = granule_load(grsrc, gs + x_side);
+    granule_vec sn = granule_load(grsrc, gn + x_side);
+
     // ---- interior pair: rows 1 and 2 pull from rows 0..3 of the band only -------------------------------------
     const bool accel = (s + 1 < a.n_steps) || a.accel_last;
     f2 ti[kQ] = {ri[0], f2{s1_1, s1_2}, f2{re[2].x, ri[2].x}, f2{s3_1, s3_2}, f2{ri[4].y, re[4].y},
@@ -1622,32 +1705,14 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
     // what rows 0 and 3 pull from inside the band (kept before the interior pair is overwritten)
     const float t4_0 = ri[4].x, t2_3 = ri[2].y;
     f2 ni[kQ];
-    float sum = relax_pair_rows(ti, blocked_i, accel ? lid_i : 0u, a.omega, a.a1, a.a2, ni);
+    float sum = 0.f;
+    if constexpr (!JOINT) sum = relax_pair_rows(ti, blocked_i, accel ? lid_i : 0u, a.omega, a.a1, a.a2, ni);
 
     // ---- edge pair: rows 0 and 3 also pull from the neighbouring bands ----------------------------------------
-    float h2, h5, h6, h4, h7, h8;
     {
-      const unsigned gs = from_south + (unsigned)slot * slot_bytes, gn = from_north + (unsigned)slot * slot_bytes;
-      // the wave's first lane also needs the column west of it, its last lane the column east of it
-      const bool first = (lane == 0), last = (lane == 63);
-      // (every lane issues the second load, the inner lanes for their own column again: four loads in flight, one
-      // wait, no divergent branch in the spin)
-      const unsigned x_side = (unsigned)(first ? xw : (last ? xe : x)) * 16u;
       long long t_start = 0;
       for (unsigned spins = 0;; spins++) {
-        const granule_vec cs = granule_load(grsrc, gs + (unsigned)x * 16u);
-        const granule_vec cn = granule_load(grsrc, gn + (unsigned)x * 16u);
-        const granule_vec ss = granule_load(grsrc, gs + x_side);
-        const granule_vec sn = granule_load(grsrc, gn + x_side);
         const bool ok = ((unsigned)cs.w == tag) & ((unsigned)cn.w == tag) & ((unsigned)ss.w == tag) & ((unsigned)sn.w == tag);
-        // south: {2, 5, 6} of its row 3; north: {4, 7, 8} of its row 0; 5 and 8 come from the west column, 6 and 7 from the east
-        const float side_s = __uint_as_float((unsigned)(first ? ss.y : ss.z)), side_n = __uint_as_float((unsigned)(first ? sn.z : sn.y));
-        h2 = __uint_as_float((unsigned)cs.x);
-        h4 = __uint_as_float((unsigned)cn.x);
-        h5 = shift_from_west(__uint_as_float((unsigned)cs.y), side_s);
-        h6 = shift_from_east(__uint_as_float((unsigned)cs.z), side_s);
-        h7 = shift_from_east(__uint_as_float((unsigned)cn.y), side_n);
-        h8 = shift_from_west(__uint_as_float((unsigned)cn.z), side_n);
         if (__all(ok)) break;
         // not there yet: every so often look at the clock and at what the other workgroups say (wave-uniform)
         if ((spins & 63u) == 63u) {
@@ -1661,12 +1726,25 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
           }
         }
         __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");  // the loads must be issued again in every spin
+        cs = granule_load(grsrc, gs + (unsigned)x * 16u);
+        cn = granule_load(grsrc, gn + (unsigned)x * 16u);
+        ss = granule_load(grsrc, gs + x_side);
+        sn = granule_load(grsrc, gn + x_side);
       }
     }
+    // south: {2, 5, 6} of its row 3; north: {4, 7, 8} of its row 0; 5 and 8 come from the west column, 6 and 7 from the east
+    const float side_s = __uint_as_float((unsigned)(first ? ss.y : ss.z)), side_n = __uint_as_float((unsigned)(first ? sn.z : sn.y));
+    const float h2 = __uint_as_float((unsigned)cs.x), h4 = __uint_as_float((unsigned)cn.x);
+    const float h5 = shift_from_west(__uint_as_float((unsigned)cs.y), side_s);
+    const float h6 = shift_from_east(__uint_as_float((unsigned)cs.z), side_s);
+    const float h7 = shift_from_east(__uint_as_float((unsigned)cn.y), side_n);
+    const float h8 = shift_from_west(__uint_as_float((unsigned)cn.z), side_n);
     f2 te[kQ] = {re[0], f2{s1_0, s1_3}, f2{h2, t2_3}, f2{s3_0, s3_3}, f2{t4_0, h4},
                  f2{h5, s5_2}, f2{h6, s6_2}, f2{s7_1, h7}, f2{s8_1, h8}};
     f2 ne[kQ];
-    sum += relax_pair_rows(te, blocked_e, accel ? lid_e : 0u, a.omega, a.a1, a.a2, ne);
+    if constexpr (JOINT) sum = relax_two_pairs_rows(ti, te, blocked_i, blocked_e, accel ? lid_i : 0u, accel ? lid_e : 0u, a.omega, a.a1, a.a2, ni, ne);
+    else sum += relax_pair_rows(te, blocked_e, accel ? lid_e : 0u, a.omega, a.a1, a.a2, ne);
 #pragma unroll
     for (int k = 0; k < kQ; k++) { ri[k] = ni[k]; re[k] = ne[k]; }
     // blocked cells report 0; sum over the wave, one partial per wave into LDS (summed after the next barrier)
@@ -1678,8 +1756,7 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
 
   __syncthreads();
   if (a.n_steps > 0 && wave == 0) {
-    float v = (lane < n_waves) ? wave_part[(a.n_steps - 1) & 1][lane] : 0.f;
-    for (int off = 8; off > 0; off >>= 1) v += __shfl_down(v, off, 16);
+    const float v = row16_sum_dpp((lane < n_waves) ? wave_part[(a.n_steps - 1) & 1][lane] : 0.f);
     if (lane == 0) a.partials[(long)(a.n_steps - 1) * bands + b] = v;
   }
   float* out = a.dst + (long)(kResidentRows * b) * a.row_pitch + x;

@@ -1,6 +1,6 @@
 """The resident-lattice kernel (lbm::resident_band): one launch per lbm_run call, the lattice in registers, seam rows
 between 4-row bands through tagged L2 granules.  Default for single periodic slabs of at most 1024 x 4*CUs cells and
-calls of >= 16 timesteps -- i.e. for the reference's own data sets.  Lattice bit-identical to the oracle."""
+calls long enough to pay for a launch (8 steps at 1024^2, 128 at 128^2) -- i.e. for the reference's own data sets.  Lattice bit-identical to the oracle."""
 import numpy as np
 import pytest
 
@@ -25,9 +25,11 @@ def run_resident(lbm, oracle, p, ob, cells, calls, math="exact"):
 
 @pytest.mark.parametrize("name,calls", [("128x128", [37]), ("128x128", [16, 1, 40, 3, 17]), ("128x256", [300]),
                                         ("256x256", [50]), ("1024x1024", [24])])
-def test_resident_reference_datasets_bitwise(lbm, oracle, datasets, name, calls):
-    """Default path on the reference's data sets: calls of >= 16 steps run resident, shorter ones launch per pass;
-    the lid row, the walls and the periodic seam between the last and the first band are all live."""
+def test_resident_reference_datasets_bitwise(lbm, oracle, datasets, monkeypatch, name, calls):
+    """The reference's data sets: calls of >= 16 steps run resident here (the default threshold grows as the grid
+    shrinks: 8 / 32 / 128 steps), shorter ones launch per pass; the lid row, the walls and the periodic seam between
+    the last and the first band are all live."""
+    monkeypatch.setenv("LBM_RESIDENT_MIN_STEPS", "16")
     p, ob = datasets(name)
     cells = oracle.init_cells(p)
     ref, ref_av, got, got_av, fields = run_resident(lbm, oracle, p, ob, cells, calls)
@@ -37,12 +39,19 @@ def test_resident_reference_datasets_bitwise(lbm, oracle, datasets, name, calls)
     assert np.array_equal(fields["pressure"].view(np.uint32), want["pressure"].view(np.uint32))
 
 
-@pytest.mark.parametrize("nx,ny", [(64, 8), (64, 12), (128, 16), (192, 40), (320, 8), (512, 64), (704, 20), (1024, 64),
-                                   (1024, 1024), (960, 36)])
-def test_resident_random_lattices_bitwise(lbm, oracle, monkeypatch, nx, ny):
+@pytest.mark.parametrize("nx,ny,env", [(64, 8, {}), (64, 12, {"LBM_RESIDENT_JOINT": "0"}), (128, 16, {}), (192, 40, {}),
+                                       (256, 64, {"LBM_RESIDENT_JOINT": "0"}), (320, 8, {}), (320, 24, {"LBM_RESIDENT_JOINT": "1"}),
+                                       (512, 64, {}), (512, 32, {"LBM_RESIDENT_JOINT": "1"}), (704, 20, {}), (1024, 64, {}),
+                                       (1024, 1024, {}), (960, 36, {}), (1024, 128, {"LBM_RESIDENT_XCD": "0"}),
+                                       (128, 64, {"LBM_RESIDENT_XCD": "0"}), (192, 36, {})])
+def test_resident_random_lattices_bitwise(lbm, oracle, monkeypatch, nx, ny, env):
     """Random lattices with random obstacles (also on the seam rows and at the wave edges), both periodic wraps live,
-    widths of 1 to 16 waves -- full and partly filled workgroups --, 2 to 256 bands; every call resident."""
+    widths of 1 to 16 waves -- full and partly filled workgroups --, 2 to 256 bands; every call resident.  Both orders
+    of a step (interior pair before the halo wait / both pairs together behind it), seams kept in an XCD's L2 where
+    both bands run on it and written through everywhere (band counts that are and are not multiples of 8)."""
     monkeypatch.setenv("LBM_RESIDENT_MIN_STEPS", "1")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     p, ob, cells = random_case(lbm, nx, ny, nx * 3 + ny, blocked_frac=0.04, walls=False)
     calls = [1, 2, 19, 5] if nx * ny <= 300000 else [1, 6]
     ref, ref_av, got, got_av, _ = run_resident(lbm, oracle, p, ob, cells, calls)
