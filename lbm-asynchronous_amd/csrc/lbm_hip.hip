@@ -1692,7 +1692,9 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
       // K >= 3 (2 waves per SIMD, bound by instruction issue): the waves run in rounds of 2048 and every wave of a round
       // takes band + 2(K-1) row iterations, so the cost of a band height is rounds x iterations (8192^2, K = 4: 46 rows
       // = 6086 waves = 2.97 rounds 0.274 ms per step; 55 rows = 2.47 rounds 0.288; 58 rows 0.300; 64 rows 0.309;
-      // 24 / 32 rows 0.293 / 0.296; K = 3: 44 rows = 3.10 rounds 0.389, 46 rows 0.350).
+      // 24 / 32 rows 0.293 / 0.296; K = 3: 44 rows = 3.10 rounds 0.389, 46 rows 0.350).  Round 3: heights up to 160
+      // rows -- ONE round of 2040 waves at 8192^2 (137 rows: 6 warm-up rows per 137 instead of per 46) 0.2691 vs
+      // 0.2757 at 46, 0.2736 at 69 (two rounds), 0.284 at 92, 0.334 at 119, 0.321 at 180 (same box).
       const long interior = (n_slabs > 1 || world > 1 || halo_on) ? rows_eff + 4 - 2 * c->pass_steps : rows_eff;
       const long r_int = interior > 1 ? interior : 1;
       const int warm = 2 * (c->pass_steps - 1);
@@ -1702,7 +1704,8 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
         // rounds of 2048 resident waves; a last round that fills at most half of the slots leaves one wave per SIMD,
         // which then runs at nearly twice the speed
         double best = -1.0;
-        for (int b = 8; b <= 64; b++) {
+        const int b_max = env_int("LBM_BAND_MAX", 160);
+        for (int b = 8; b <= b_max; b++) {
           const long waves = (long)c->n_strips * ceil_div(r_int, b);
           const long full = waves / 2048, rest = waves % 2048;
           double rounds = (double)full + (rest == 0 ? 0.0 : (rest > 1024 ? 1.0 : 0.6));

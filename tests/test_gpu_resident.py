@@ -84,9 +84,10 @@ def test_resident_guard_paths_bitwise(lbm, oracle):
     assert np.array_equal(ref.view(np.uint32), got.view(np.uint32))
 
 
-def test_resident_fast_mode_uses_the_exact_kernel(lbm, oracle, datasets):
+def test_resident_fast_mode_uses_the_exact_kernel(lbm, oracle, datasets, monkeypatch):
     """LBM_MATH_FAST on these grids is served by the resident kernel (exact arithmetic: the faster kernel here, and
     trivially inside the fast mode's tolerance)."""
+    monkeypatch.setenv("LBM_RESIDENT_MIN_STEPS", "16")
     p, ob = datasets("128x128")
     cells = oracle.init_cells(p)
     ref, ref_av, got, got_av, _ = run_resident(lbm, oracle, p, ob, cells, [64], math="fast")
@@ -116,6 +117,7 @@ def test_resident_gives_up_instead_of_hanging(lbm, datasets, monkeypatch):
     """A band whose workgroup never runs (simulated) starves its neighbours: they give up after the bound, the status
     reaches the host as an error from the next call that synchronises -- an error, never a hang."""
     import time
+    monkeypatch.setenv("LBM_RESIDENT_MIN_STEPS", "16")
     monkeypatch.setenv("LBM_RESIDENT_ABSENT_BAND", "5")
     monkeypatch.setenv("LBM_RESIDENT_TIMEOUT_MS", "200")
     p, ob = datasets("128x128")
