@@ -511,7 +511,7 @@ int launch_step2(lbm_ctx* c, int s, hipStream_t stream, int row_first, int row_e
   return q_kernel(c, stream, reinterpret_cast<const void*>(kernel), dim3(waves), dim3(64), args, done);
 }
 
-// k (2..3) timesteps in one pass over the rows [row_first, row_end) of slab s (4 cells per lane), cut into band_count
+// k (2..4) timesteps in one pass over the rows [row_first, row_end) of slab s (4 cells per lane), cut into band_count
 // bands of band_rows rows that start band_pitch rows apart; partials of step t+j go to slot slot_fill + j
 int launch_stepk(lbm_ctx* c, int s, hipStream_t stream, int k, int row_first, int row_end, int band_rows,
                  int band_pitch, int band_count, int part_offset, bool accel_after, hipEvent_t done = nullptr) {
@@ -550,13 +550,16 @@ int launch_stepk(lbm_ctx* c, int s, hipStream_t stream, int k, int row_first, in
   }
   typedef void (*fn)(const lbm::StepKArgs);
   // [math][nontemporal stores][k - 2][prefetch]
+  // (K = 4 with the next row prefetched does not fit the register file -- 112 bytes of scratch per lane -- so that
+  // request runs the kernel without prefetch: same results)
 #define LBM_K_ROW(M, N) {{lbm::stepk_stream<M, N, 4, 2, false>, lbm::stepk_stream<M, N, 4, 2, true>}, \
                          {lbm::stepk_stream<M, N, 4, 3, false>, lbm::stepk_stream<M, N, 4, 3, true>}, \
-                         {lbm::stepk_stream<M, N, 4, 4, false>, lbm::stepk_stream<M, N, 4, 4, true>}}
+                         {lbm::stepk_stream<M, N, 4, 4, false>, lbm::stepk_stream<M, N, 4, 4, false>}}
   static const fn table[2][2][3][2] = {{LBM_K_ROW(0, false), LBM_K_ROW(0, true)}, {LBM_K_ROW(1, false), LBM_K_ROW(1, true)}};
 #undef LBM_K_ROW
   // exact arithmetic on pairs of cells (v_pk_* instructions): [nontemporal stores][k - 2][prefetch][windows in LDS]
-#define LBM_PK(N, KK, PF) {lbm::stepk_pk<N, KK, PF, 0>, lbm::stepk_pk<N, KK, PF, 1>, lbm::stepk_pk<N, KK, PF, (KK > 2 ? 2 : 1)>}
+  // (K = 4 prefetches only with two of its three windows in LDS: with fewer it spills, and runs without prefetch)
+#define LBM_PK(N, KK, PF) {lbm::stepk_pk<N, KK, (PF && KK < 4), 0>, lbm::stepk_pk<N, KK, (PF && KK < 4), 1>, lbm::stepk_pk<N, KK, PF, (KK > 2 ? 2 : 1)>}
 #define LBM_PK_ROW(N) {{LBM_PK(N, 2, false), LBM_PK(N, 2, true)}, {LBM_PK(N, 3, false), LBM_PK(N, 3, true)}, \
                        {LBM_PK(N, 4, false), LBM_PK(N, 4, true)}}
   // [nontemporal stores][k - 2][prefetch][windows in LDS]  (the QUAD form of stepk_pk -- both pairs of a lane in one
@@ -572,7 +575,7 @@ int launch_stepk(lbm_ctx* c, int s, hipStream_t stream, int k, int row_first, in
 #undef LBM_PK1_ROW
 #undef LBM_PK1
   const int lds_windows = c->lds_windows < k ? c->lds_windows : k - 1;
-  const bool packed = c->packed && c->math_mode == LBM_MATH_EXACT;
+  const bool packed = c->packed != 0;  // the packed kernels have one arithmetic (the exact one) and serve both math modes
   const fn kernel = (packed && c->lane_cells == 2) ? table_pk1[c->nts][k - 2][c->prefetch ? 1 : 0][lds_windows ? 1 : 0]
                     : packed ? table_pk[c->nts][k - 2][c->prefetch ? 1 : 0][lds_windows]
                            : table[c->math_mode == LBM_MATH_EXACT ? 0 : 1][c->nts][k - 2][c->prefetch ? 1 : 0];
@@ -584,7 +587,7 @@ int launch_stepk(lbm_ctx* c, int s, hipStream_t stream, int k, int row_first, in
 int launch_pass(lbm_ctx* c, int s, hipStream_t stream, int k, int row_first, int row_end, int band_rows,
                 int band_pitch, int band_count, int part_offset, bool accel_after, hipEvent_t done = nullptr) {
   if ((c->lane_cells == 4 && (k > 2 || c->prefetch || c->xcd_chunk || c->use_stepk || c->packed)) ||
-      (c->lane_cells == 2 && c->packed && c->math_mode == LBM_MATH_EXACT))
+      (c->lane_cells == 2 && c->packed))
     return launch_stepk(c, s, stream, k, row_first, row_end, band_rows, band_pitch, band_count, part_offset, accel_after, done);
   return launch_step2(c, s, stream, row_first, row_end, band_rows, band_pitch, band_count, part_offset, accel_after, done);
 }
@@ -1331,6 +1334,13 @@ bool validate_params(const lbm_params* p) {
   return p && p->nx >= 1 && p->ny >= 2 && p->max_iters >= 0 && (long)p->nx * (long)p->ny <= 2147483647L;
 }
 
+// a device staging buffer that is freed on every way out of the scope that allocated it
+struct DeviceTemp {
+  void* p = nullptr;
+  ~DeviceTemp() { if (p) (void)hipFree(p); }
+  template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
 // Build one slab: allocate, build the mask on the device, fill the lattice.
 int build_slab(lbm_ctx* c, int s, const ObstacleSource& obst, const float* cells_aos) {
   Slab& sl = c->slab[s];
@@ -1389,19 +1399,20 @@ int build_slab(lbm_ctx* c, int s, const ObstacleSource& obst, const float* cells
       const size_t tn = (size_t)obst.tile_nx * obst.tile_ny;
       std::vector<unsigned char> t8(tn);
       for (size_t i = 0; i < tn; i++) t8[i] = obst.data[i] ? 1 : 0;
-      unsigned char* tile_dev = nullptr;
-      HIP_TRY(LBM_FAILURE, hipMalloc(&tile_dev, tn));
+      DeviceTemp tile_buf;
+      HIP_TRY(LBM_FAILURE, hipMalloc(&tile_buf.p, tn));
+      unsigned char* tile_dev = tile_buf.as<unsigned char>();
       HIP_TRY(LBM_FAILURE, hipMemcpyAsync(tile_dev, t8.data(), tn, hipMemcpyHostToDevice, sl.compute));
       hipLaunchKernelGGL(lbm::mask_from_tile, dim3(ceil_div((long)p.nx * mrows, 256)), dim3(256), 0, sl.compute, tile_dev,
                          obst.tile_nx, obst.tile_ny, sl.mask_alloc, p.nx, c->pitch, sl.row_first - kMaskHalo, mrows, p.ny);
       HIP_TRY(LBM_FAILURE, hipGetLastError());
       HIP_TRY(LBM_FAILURE, hipStreamSynchronize(sl.compute));
-      HIP_TRY(LBM_FAILURE, hipFree(tile_dev));
     } else {
       long chunk_rows = (32L << 20) / ((long)p.nx * sizeof(int));
       if (chunk_rows < 1) chunk_rows = 1;
-      int* stage = nullptr;
-      HIP_TRY(LBM_FAILURE, hipMalloc(&stage, (size_t)chunk_rows * p.nx * sizeof(int)));
+      DeviceTemp stage_buf;
+      HIP_TRY(LBM_FAILURE, hipMalloc(&stage_buf.p, (size_t)chunk_rows * p.nx * sizeof(int)));
+      int* stage = stage_buf.as<int>();
       for (int r = 0; r < mrows;) {
         // source row of mask row r, and how many rows from there are contiguous in the source
         long src_row;
@@ -1422,7 +1433,6 @@ int build_slab(lbm_ctx* c, int s, const ObstacleSource& obst, const float* cells
         HIP_TRY(LBM_FAILURE, hipStreamSynchronize(sl.compute));  // the staging buffer is reused
         r += run;
       }
-      HIP_TRY(LBM_FAILURE, hipFree(stage));
     }
     // fluid cells of the owned rows (the reference counts them while parsing, MPI_Waitall/d2q9-bgk.c:794-804)
     unsigned long long* cnt = reinterpret_cast<unsigned long long*>(sl.scratch);
@@ -1449,8 +1459,9 @@ int build_slab(lbm_ctx* c, int s, const ObstacleSource& obst, const float* cells
     const int chunk_rows = (int)(((64L << 20) / ((long)p.nx * lbm::kQ * sizeof(float))) > 0
                                      ? ((64L << 20) / ((long)p.nx * lbm::kQ * sizeof(float)))
                                      : 1);
-    float* stage = nullptr;
-    HIP_TRY(LBM_FAILURE, hipMalloc(&stage, (size_t)chunk_rows * p.nx * lbm::kQ * sizeof(float)));
+    DeviceTemp stage_buf;
+    HIP_TRY(LBM_FAILURE, hipMalloc(&stage_buf.p, (size_t)chunk_rows * p.nx * lbm::kQ * sizeof(float)));
+    float* stage = stage_buf.as<float>();
     for (int r0 = 0; r0 < sl.rows; r0 += chunk_rows) {
       const int nr = (sl.rows - r0 < chunk_rows) ? sl.rows - r0 : chunk_rows;
       const size_t n = (size_t)nr * p.nx * lbm::kQ;
@@ -1461,7 +1472,6 @@ int build_slab(lbm_ctx* c, int s, const ObstacleSource& obst, const float* cells
       HIP_TRY(LBM_FAILURE, hipGetLastError());
       HIP_TRY(LBM_FAILURE, hipStreamSynchronize(sl.compute));
     }
-    HIP_TRY(LBM_FAILURE, hipFree(stage));
   }
   HIP_TRY(LBM_FAILURE, hipStreamSynchronize(sl.compute));
   return LBM_SUCCESS;
@@ -1496,8 +1506,14 @@ StreamPlan plan_stream(const lbm_params* params, int parts, bool halo_on, int ma
   // steps and runs K = 3 as the packed kernel (124 VGPRs, 4 waves per SIMD): 1024^2 9.4 vs 10.7 us (K = 2), 1280^2
   // 12.4 vs 15.2 (four-cell K = 4), 1536^2 15.2 vs 20.9, 1792^2 20.2 vs 22.3; from 2048^2 the four-cell form wins
   // (24.9 vs 25.6-27.5).
-  const bool exact_packed = (math_mode == LBM_MATH_EXACT) && env_int("LBM_PACKED", 1) != 0;
-  pl.pass_steps = env_int("LBM_PASS_STEPS", pl.lane_cells == 4 ? (math_mode == LBM_MATH_EXACT ? 4 : 3) : (exact_packed ? 3 : 2));
+  // FAST math (reciprocal + FMA, scalar) is the faster arithmetic only in the one-step and LDS-tile kernels.  The
+  // multi-step stream kernels run the packed EXACT collision in both modes: it is faster than the scalar fast form
+  // (8192^2: 0.27 vs 0.345 ms per step) and at K = 4 it already sits at the DRAM bound of its access pattern (5.8 GB per
+  // launch at 5.4-5.8 TB/s), so a packed fast form could not be faster -- and exact results meet the fast mode's
+  // tolerance trivially.  LBM_PACKED=0 selects the scalar kernels (fast math: K = 3 / 2).
+  (void)math_mode;
+  const bool exact_packed = env_int("LBM_PACKED", 1) != 0;
+  pl.pass_steps = env_int("LBM_PASS_STEPS", pl.lane_cells == 4 ? (exact_packed ? 4 : 3) : (exact_packed ? 3 : 2));
   if (pl.pass_steps < 2 || pl.pass_steps > kHaloRows) pl.pass_steps = 2;
   if (pl.lane_cells != 4 && !exact_packed) pl.pass_steps = 2;  // the scalar two-cell kernel (step2_stream) is two-step
   // across slabs a K-step pass needs slabs of at least 2K rows (the stream kernel at all: 4); a periodic slab at least K
@@ -1640,8 +1656,7 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
   // without prefetch / LDS | scalar K = 3: 16384^2 1091 | 1097 | 1355, 12288^2 640 | 652 | 838, 6144^2 180 | 187 | 233,
   // 4096^2 75.3 | 78.1 | 94.7, 3072^2 45.6 | 45.3 | 59.0, 2048^2 24.9 | 26.3 | 31.9; a rank's share through the halo
   // pipeline 8192x1024 45.1 | 46.7 | 55.3, 8192x2048 77.5 | 81.4 | 98.9, 8192x4096 149 | 152 | 187.
-  c->packed = env_int("LBM_PACKED", math_mode == LBM_MATH_EXACT ? 1 : 0) ? 1 : 0;
-  if (math_mode != LBM_MATH_EXACT) c->packed = 0;
+  c->packed = env_int("LBM_PACKED", 1) ? 1 : 0;  // both math modes (see plan_stream)
   c->lds_windows = env_int("LBM_LDS_WINDOWS", (c->packed && c->pass_steps == 4) ? 2 : 0);
   if (c->lds_windows < 0 || c->lds_windows > 2 || !c->packed) c->lds_windows = 0;
   // scalar K = 4 with prefetch spills (245 + 36 VGPRs); the packed K = 4 needs its LDS windows for it
@@ -1848,10 +1863,6 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
     }
     c->fluid_cells = (int)fluid;
   }
-  // one issuing thread per slab when one process drives several slabs: opt-in (LBM_THREADS=1).
-  // With several slabs on ONE device it is slower (the runtime serialises calls to a device:
-  // 65 vs 53 us per step for 2 slabs); whether it pays with one device per slab could not be
-  // measured on the 1-GPU box.
   // One issuing thread per slab when one process drives several slabs on DISTINCT devices (LBM_GPUS=n on a multi-GPU
   // node): a pass enqueues ~10 runtime calls per slab, 25-30 us on one thread -- more than an 8-GPU pass of 8192^2
   // takes on the devices.  With several slabs on ONE device it is slower (the runtime serialises calls to a device:
@@ -2163,8 +2174,9 @@ int lbm_read_cells(lbm_ctx* c, float* cells_aos) {
   for (int s = 0; s < c->n_slabs; s++) {
     Slab& sl = c->slab[s];
     HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
-    float* stage = nullptr;
-    HIP_TRY(LBM_FAILURE, hipMalloc(&stage, (size_t)chunk_rows * nx * lbm::kQ * sizeof(float)));
+    DeviceTemp stage_buf;
+    HIP_TRY(LBM_FAILURE, hipMalloc(&stage_buf.p, (size_t)chunk_rows * nx * lbm::kQ * sizeof(float)));
+    float* stage = stage_buf.as<float>();
     for (int r0 = 0; r0 < sl.rows; r0 += (int)chunk_rows) {
       const int nr = (sl.rows - r0 < chunk_rows) ? sl.rows - r0 : (int)chunk_rows;
       const size_t n = (size_t)nr * nx * lbm::kQ;
@@ -2175,7 +2187,6 @@ int lbm_read_cells(lbm_ctx* c, float* cells_aos) {
                                           n * sizeof(float), hipMemcpyDeviceToHost, sl.compute));
       HIP_TRY(LBM_FAILURE, hipStreamSynchronize(sl.compute));
     }
-    HIP_TRY(LBM_FAILURE, hipFree(stage));
   }
   return LBM_SUCCESS;
 }
@@ -2190,9 +2201,10 @@ int lbm_read_final_state(lbm_ctx* c, float* u_x, float* u_y, float* u_mag, float
   for (int s = 0; s < c->n_slabs; s++) {
     Slab& sl = c->slab[s];
     HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
-    float* stage = nullptr;
+    DeviceTemp stage_buf;
     const size_t chunk_cells = (size_t)chunk_rows * nx;
-    HIP_TRY(LBM_FAILURE, hipMalloc(&stage, 4 * chunk_cells * sizeof(float)));
+    HIP_TRY(LBM_FAILURE, hipMalloc(&stage_buf.p, 4 * chunk_cells * sizeof(float)));
+    float* stage = stage_buf.as<float>();
     for (int r0 = 0; r0 < sl.rows; r0 += (int)chunk_rows) {
       const int nr = (sl.rows - r0 < chunk_rows) ? sl.rows - r0 : (int)chunk_rows;
       const size_t n = (size_t)nr * nx;
@@ -2206,7 +2218,6 @@ int lbm_read_final_state(lbm_ctx* c, float* u_x, float* u_y, float* u_mag, float
                                             hipMemcpyDeviceToHost, sl.compute));
       HIP_TRY(LBM_FAILURE, hipStreamSynchronize(sl.compute));
     }
-    HIP_TRY(LBM_FAILURE, hipFree(stage));
   }
   return LBM_SUCCESS;
 }

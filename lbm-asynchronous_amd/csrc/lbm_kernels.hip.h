@@ -754,7 +754,7 @@ struct Window {
 };
 
 template <int MATH, bool NTS, int C, int K, bool PREFETCH>
-__global__ __launch_bounds__(64, (K >= 3 || PREFETCH) ? 2 : 3) void stepk_stream(const StepKArgs a) {
+__global__ __launch_bounds__(64, (K >= 3 || PREFETCH || MATH == 0) ? 2 : 3) void stepk_stream(const StepKArgs a) {
   static_assert(K >= 2 && K <= 4 && (C == 4 || K == 2), "one halo lane per side covers K <= C steps");
   typedef typename RowPull<C>::vec vec;
   const int lane = threadIdx.x;

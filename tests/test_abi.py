@@ -124,17 +124,20 @@ def test_halo_plan_pairs_up_around_the_ring(lbm):
 
 
 def test_plan_halo_depth_follows_the_kernel_policy(lbm, monkeypatch):
-    for k in ("LBM_FUSE2", "LBM_LANE_CELLS", "LBM_PASS_STEPS", "LBM_VEC4"):
+    for k in ("LBM_FUSE2", "LBM_LANE_CELLS", "LBM_PASS_STEPS", "LBM_VEC4", "LBM_PACKED"):
         monkeypatch.delenv(k, raising=False)
     small = lbm.Params(128, 256, 10, 10, 0.1, 0.005, 1.85)
     big = lbm.Params(8192, 8192, 10, 10, 0.1, 0.01, 1.85)
     thin = lbm.Params(128, 40, 10, 10, 0.1, 0.005, 1.85)
     ragged = lbm.Params(130, 64, 10, 10, 0.1, 0.005, 1.85)
     assert lbm.plan_halo_depth(small, 2) == 3          # three-step packed kernel, 2 cells per lane
-    assert lbm.plan_halo_depth(small, 2, "fast") == 2  # fast math: the scalar two-step kernel
+    assert lbm.plan_halo_depth(small, 2, "fast") == 3  # the packed stream kernels serve both math modes
     assert lbm.plan_halo_depth(big, 8) == 4            # 8192x1024 per rank: four-step packed kernel
-    assert lbm.plan_halo_depth(big, 2) == 4 and lbm.plan_halo_depth(big, 2, "fast") == 3
+    assert lbm.plan_halo_depth(big, 2) == 4 and lbm.plan_halo_depth(big, 2, "fast") == 4
     assert lbm.plan_halo_depth(ragged, 2) == 1         # nx % 4 != 0: one step per pass
     assert lbm.plan_halo_depth(thin, 8) == 2           # 5-row slabs: too thin for three-row halos
+    monkeypatch.setenv("LBM_PACKED", "0")               # the scalar kernels: fast math runs K = 2 / 3
+    assert lbm.plan_halo_depth(small, 2, "fast") == 2 and lbm.plan_halo_depth(big, 2, "fast") == 3
+    monkeypatch.delenv("LBM_PACKED")
     monkeypatch.setenv("LBM_PASS_STEPS", "2")
     assert lbm.plan_halo_depth(big, 8) == 2

@@ -127,12 +127,16 @@ def test_cli_stale_halo_mode_deviation_is_bounded(lbm, golden, tmp_path, name, g
 
 
 @pytest.mark.parametrize("name", ["128x128", "128x256", "256x256", "1024x1024"])
-@pytest.mark.parametrize("fuse", ["0", "1"])
+@pytest.mark.parametrize("fuse", ["0", "1", "1-scalar", "default"])
 def test_fast_mode_full_run_passes_check_rule(lbm, datasets, golden, monkeypatch, name, fuse):
-    """FAST arithmetic (reciprocal + FMA) over the reference's full iteration counts, with the
-    one-step and the two-steps-per-pass kernel: passes check.py's 1 % gate against the
-    double-precision goldens and against SerialCode's fp32 output on all four reference grids."""
-    monkeypatch.setenv("LBM_FUSE2", fuse)
+    """LBM_MATH_FAST over the reference's full iteration counts -- with the one-step kernel (reciprocal + FMA), the
+    stream kernels it is served by (packed exact collision), the scalar fast stream kernels (LBM_PACKED=0) and the
+    default of these grids (the resident kernel): passes check.py's 1 % gate against the double-precision goldens
+    and against SerialCode's fp32 output on all four reference grids."""
+    if fuse != "default":
+        monkeypatch.setenv("LBM_FUSE2", fuse[0])
+    if fuse == "1-scalar":
+        monkeypatch.setenv("LBM_PACKED", "0")
     p, ob = datasets(name)
     gold = np.load(os.path.join(golden, "check_goldens.npz"))
     ref = np.load(os.path.join(golden, f"serialcode_{name}.npz"))

@@ -195,10 +195,12 @@ def test_guard_paths_stay_bit_exact(lbm, oracle, monkeypatch, kernel):
 
 
 def test_fast_math_three_step_kernel_within_check_tolerance(lbm, oracle, datasets, monkeypatch):
-    """FAST arithmetic on large grids runs the scalar stream kernel with three steps per pass; forced here at test
-    size (4 cells per lane) and held to the check.py rule against the oracle, like the other fast-mode kernels."""
+    """The scalar stream kernel with FAST arithmetic and three steps per pass (LBM_PACKED=0; by default both math
+    modes run the packed exact stream kernels, which are faster); forced here at test size (4 cells per lane) and
+    held to the check.py rule against the oracle, like the other fast-mode kernels."""
     monkeypatch.setenv("LBM_FUSE2", "1")
     monkeypatch.setenv("LBM_LANE_CELLS", "4")
+    monkeypatch.setenv("LBM_PACKED", "0")
     p, ob = datasets("128x128")
     cells = oracle.init_cells(p)
     steps = 2000
