@@ -568,7 +568,7 @@ int launch_stepk(lbm_ctx* c, int s, hipStream_t stream, int k, int row_first, in
 #undef LBM_PK_ROW
 #undef LBM_PK
   // two cells per lane (one pair): [nontemporal stores][k - 2][prefetch][windows in LDS: 0, 1]
-#define LBM_PK1(N, KK, PF) {lbm::stepk_pk<N, KK, PF, 0, false, 1>, lbm::stepk_pk<N, KK, PF, 1, false, 1>}
+#define LBM_PK1(N, KK, PF) {lbm::stepk_pk<N, KK, (PF && KK < 4), 0, false, 1>, lbm::stepk_pk<N, KK, PF, 1, false, 1>}
 #define LBM_PK1_ROW(N) {{LBM_PK1(N, 2, false), LBM_PK1(N, 2, true)}, {LBM_PK1(N, 3, false), LBM_PK1(N, 3, true)}, \
                         {LBM_PK1(N, 4, false), LBM_PK1(N, 4, true)}}
   static const fn table_pk1[2][3][2][2] = {LBM_PK1_ROW(false), LBM_PK1_ROW(true)};
@@ -1118,6 +1118,7 @@ int run_resident(lbm_ctx* c, int n_steps) {
     a.gran = sl.res_gran;
     a.gran_bytes = (unsigned)((2UL * c->resident_bands * 2 * c->p.nx + c->resident_bands) * sizeof(uint4));
     a.xcd_affinity = env_int("LBM_RESIDENT_XCD", 1) ? 1 : 0;
+    a.poll_sleep = env_int("LBM_RESIDENT_SLEEP", c->p.nx > 512 ? 4 : 1);
     a.epoch0 = (unsigned)(c->steps_done + t);
     a.partials = sl.res_part;
     a.status = sl.res_status;

@@ -1205,16 +1205,32 @@ __global__ __launch_bounds__(64, NP == 1 ? (K > 2 ? 3 : (PREFETCH ? 2 : 4)) : 2)
   };
 
   const int n_iter = band_n + 2 * (K - 1);
+  // Row bookkeeping kept incrementally (all wave-uniform, i.e. scalar registers): the row stage 1 pulls advances by
+  // one per iteration, and stage s+1 works on the row stage 1 had s iterations ago -- so "is this the lid row" and
+  // "does this row belong to the band" are shift registers (bit s = stage s+1), and the row the last stage stores is
+  // the oldest of a K-deep history, instead of a wrap, two compares and a window test per stage, pair and iteration.
+  int r_next = wrap_row(y0 - (K - 1), a.rows, a.wrap);  // the row iteration i pulls
+  int r_hist[K];                                        // r_hist[s] = the row stage s+1 works on
+#pragma unroll
+  for (int s = 0; s < K; s++) r_hist[s] = 0;
+  unsigned lid_hist = 0, own_hist = 0;
   RowPull<C> nextp;
-  if constexpr (PREFETCH) nextp = pull_row<C>(pa, wrap_row(y0 - (K - 1), a.rows, a.wrap), x0);
+  if constexpr (PREFETCH) nextp = pull_row<C>(pa, r_next, x0);
 
   for (int i = 0; i < n_iter; i++) {
     // ---- stage 1: step t on row r, pulled from memory -------------------------------------------
-    const int r = wrap_row(y0 - (K - 1) + i, a.rows, a.wrap);
+    const int r = r_next;
+    r_next = r + 1;
+    if (a.wrap && r_next >= a.rows) r_next -= a.rows;
+#pragma unroll
+    for (int s = K - 1; s > 0; s--) r_hist[s] = r_hist[s - 1];
+    r_hist[0] = r;
+    lid_hist = (lid_hist << 1) | ((r == a.accel_row || r == a.accel_row2) ? 1u : 0u);
+    own_hist = (own_hist << 1) | ((i >= K - 1 && i < band_n + K - 1) ? 1u : 0u);
     RowPull<C> p;
     if constexpr (PREFETCH) {
       p = nextp;
-      if (i + 1 < n_iter) nextp = pull_row<C>(pa, wrap_row(y0 - (K - 1) + i + 1, a.rows, a.wrap), x0);
+      if (i + 1 < n_iter) nextp = pull_row<C>(pa, r_next, x0);
     } else {
       p = pull_row<C>(pa, r, x0);
     }
@@ -1227,8 +1243,8 @@ __global__ __launch_bounds__(64, NP == 1 ? (K > 2 ? 3 : (PREFETCH ? 2 : 4)) : 2)
 #pragma unroll
       for (int k = 0; k < kQ; k++) pairs_of(p.v[k], pl[k]);
       shifted(pl, W, E, in);
-      const bool lid = (r == a.accel_row) || (r == a.accel_row2);
-      const bool own_row = (i >= K - 1) && (i < band_n + K - 1);
+      const bool lid = (lid_hist & 1u) != 0;
+      const bool own_row = (own_hist & 1u) != 0;
       const float sp = relax_row(in, p.m, lid, cur, own_row);
       if (own_row && out_lane) sum[0] += sp;
     }
@@ -1268,10 +1284,9 @@ __global__ __launch_bounds__(64, NP == 1 ? (K > 2 ? 3 : (PREFETCH ? 2 : 4)) : 2)
         E[3] = lane_from_east<2>(pl[3][0].x);       E[6] = lane_from_east<2>(pl[6][0].x);       E[7] = lane_from_east<2>(pl[7][0].x);
         f2 in[kQ][NP];
         shifted(pl, W, E, in);
-        const int ro = wrap_row(y0 - (K - 1) + i - s, a.rows, a.wrap);
         const bool last = (s == K - 1);
-        const bool lid = ((ro == a.accel_row) || (ro == a.accel_row2)) && (!last || a.accel_after);
-        const bool own_row = (i - s >= K - 1) && (i - s < band_n + K - 1);
+        const bool lid = ((lid_hist >> s) & 1u) != 0 && (!last || a.accel_after);
+        const bool own_row = ((own_hist >> s) & 1u) != 0;
         const float sp = relax_row(in, w.m, lid, nxt, own_row);
         if (own_row && out_lane) sum[s] += sp;
       }
@@ -1300,7 +1315,7 @@ __global__ __launch_bounds__(64, NP == 1 ? (K > 2 ? 3 : (PREFETCH ? 2 : 4)) : 2)
 #pragma unroll
         for (int k = 0; k < kQ; k++) cur[p2][k] = nxt[p2][k];
       if (s == K - 1 && out_lane) {
-        const int ro = wrap_row(y0 - (K - 1) + i - s, a.rows, a.wrap);
+        const int ro = r_hist[K - 1];
         float* d_row = a.dst + (long)ro * a.row_pitch + x0;
 #pragma unroll
         for (int k = 0; k < kQ; k++) {
@@ -1480,6 +1495,7 @@ struct ResidentArgs {
   float* partials;            // partials[s * bands + b] = sum |u| over band b after step s
   int* status;                // 0, or kResidentTimeout once any workgroup gave up waiting
   long long timeout_ticks;    // bound of one halo wait in wall_clock64() ticks (100 MHz)
+  int poll_sleep;             // s_sleep argument (units of 64 clocks) between two looks at the halo granules
   int xcd_affinity;           // 1: seams inside one XCD use L2-resident stores (see resident_band); 0: sc1 everywhere
   int absent_band;            // tests: this band's workgroup returns at once, as if it had never been scheduled (-1: none)
 };
@@ -1745,7 +1761,15 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
             break;
           }
         }
-        __builtin_amdgcn_s_sleep(1);
+        // how long to stay off the issue ports before asking again: short where the wave sits alone on its SIMD
+        // (latency is everything), long where three other waves want the slots (a poll is ~25 instructions)
+        switch (a.poll_sleep) {
+          case 16: __builtin_amdgcn_s_sleep(16); break;
+          case 8: __builtin_amdgcn_s_sleep(8); break;
+          case 4: __builtin_amdgcn_s_sleep(4); break;
+          case 2: __builtin_amdgcn_s_sleep(2); break;
+          default: __builtin_amdgcn_s_sleep(1); break;
+        }
         asm volatile("" ::: "memory");  // the loads must be issued again in every spin
         cs = granule_load(grsrc, gs + (unsigned)x * 16u);
         cn = granule_load(grsrc, gn + (unsigned)x * 16u);
