@@ -53,13 +53,18 @@ def test_bench_oversubscribed_launch_fails_fast(lbm):
     assert secs < 180
 
 
-@pytest.mark.parametrize("torch_first", [False, True])
-def test_rccl_self_exchange_under_both_libraries(torch_first):
+@pytest.mark.parametrize("torch_first,forced", [(False, None), (True, None), (True, "/opt/rocm/lib/librccl.so.1")])
+def test_rccl_self_exchange_under_both_libraries(torch_first, forced):
     """The engine binds the librccl already in the process (torch's bundled one when torch was imported first -- the
-    situation of bench.py and of this test suite) or ROCm's own (the C host program): the ring of one must be
-    bit-identical to the plain periodic run under either, and the record must name the library."""
+    situation of bench.py and of this test suite) or ROCm's own (the C host program), or the file LBM_RCCL_LIB names
+    (here: ROCm's next to torch's HIP runtime): the ring of one must be bit-identical to the plain periodic run under
+    each, and the record must name the library."""
     env = dict(os.environ)
     env.pop("LBM_RCCL_LIB", None)
+    if forced:
+        if not os.path.exists(forced):
+            pytest.skip(f"{forced} not present")
+        env["LBM_RCCL_LIB"] = forced
     cmd = [sys.executable, os.path.join(ROOT, "tools", "rccl_self.py")] + (["--torch-first"] if torch_first else [])
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -68,8 +73,9 @@ def test_rccl_self_exchange_under_both_libraries(torch_first):
     assert not rec["single_slab_loaded_rccl"]                     # a single slab binds no RCCL
     rc = rec["rccl"]
     assert rc["loaded"] and rc["nranks"] == 1 and rc["n_comms"] == 1
-    if torch_first:
+    if torch_first and not forced:
         assert "/torch/lib/" in rc["library"], rc
     else:
         assert rc["library"].startswith("/opt/rocm"), rc
-    assert len([m for m in rec["mapped"] if "librccl" in m]) == 1, rec["mapped"]      # one RCCL per process
+    # one RCCL per process unless a second one was asked for by name
+    assert len([m for m in rec["mapped"] if "librccl" in m]) == (2 if forced else 1), rec["mapped"]
