@@ -356,6 +356,7 @@ struct lbm_ctx {
   int resident_min_steps = 16;      // ... this many timesteps run as launches of the resident kernel (lbm::resident_band)
   int resident_bands = 0;           // its workgroups (bands of kResidentRows rows)
   int resident_joint = 0;           // narrow grids: both pairs of a lane relaxed as one block behind the halo wait
+  int resident_rows = 4;            // rows per band: 4, or 2 where the chip has CUs to spare (one pair per lane)
   long long resident_timeout = 0;   // bound of one halo wait, wall-clock ticks
   bool resident_used = false;       // a launch is in flight / unchecked: lbm_sync reads its status
   int tile_steps = 0;               // > 0: single slab advanced by the LDS-tile kernel, this many steps per launch
@@ -1092,6 +1093,13 @@ int replay_chunks(lbm_ctx* c, int n_steps, int first_step, int* done) {
 
 int run_steps_stale(lbm_ctx* c, int n_steps, float* kernel_ms);
 
+const void* resident_kernel(int nx, int rows, int joint) {
+  if (rows == 2) return (nx > 512) ? reinterpret_cast<const void*>(lbm::resident_band<1024, false, 2>)
+                                   : reinterpret_cast<const void*>(lbm::resident_band<512, false, 2>);
+  if (nx > 512) return reinterpret_cast<const void*>(lbm::resident_band<1024>);
+  return joint ? reinterpret_cast<const void*>(lbm::resident_band<512, true>) : reinterpret_cast<const void*>(lbm::resident_band<512>);
+}
+
 // The timestep loop of a cache-resident single slab: launches of lbm::resident_band, each advancing up to
 // kResidentChunk timesteps with the lattice in registers (SerialCode/d2q9-bgk.c:166-170 as ONE launch), each followed
 // by the reduce of its per-band partial sums.  The caller has applied the first step's accelerate_flow.
@@ -1125,10 +1133,8 @@ int run_resident(lbm_ctx* c, int n_steps) {
     a.timeout_ticks = c->resident_timeout;
     a.absent_band = env_int("LBM_RESIDENT_ABSENT_BAND", -1);  // tests of the give-up path
     void* args[] = {&a};
-    const void* fn = (c->p.nx > 512) ? reinterpret_cast<const void*>(lbm::resident_band<1024>)
-                     : (c->resident_joint ? reinterpret_cast<const void*>(lbm::resident_band<512, true>)
-                                          : reinterpret_cast<const void*>(lbm::resident_band<512>));
-    HIP_TRY(LBM_FAILURE, hipLaunchKernel(fn, dim3(c->resident_bands), dim3(c->p.nx), args, 0, sl.compute));
+    HIP_TRY(LBM_FAILURE, hipLaunchKernel(resident_kernel(c->p.nx, c->resident_rows, c->resident_joint), dim3(c->resident_bands),
+                                         dim3(c->p.nx), args, 0, sl.compute));
     hipLaunchKernelGGL(lbm::reduce_band_partials, dim3(n), dim3(64), 0, sl.compute, (const float*)sl.res_part,
                        c->resident_bands, sl.tot_u, c->steps_done + t);
     HIP_TRY(LBM_FAILURE, hipGetLastError());
@@ -1771,18 +1777,23 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
     bool other_kernel = false;
     for (const char* name : selectors) other_kernel = other_kernel || getenv(name) != nullptr;
     const int nx = params->nx, ny = params->ny;
-    const bool shape_ok = nx % 64 == 0 && nx >= 64 && nx <= 1024 && ny % lbm::kResidentRows == 0 && ny >= 2 * lbm::kResidentRows;
+    int cus = 0;
+    const int dev = c->slab[0].device;
+    if (hipSetDevice(dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+    // rows per band: 2 (one pair per lane) where every band still gets a CU of its own, else 4 (us per step, 4 | 2 rows:
+    // 128^2 1.88 | 1.54, 128x256 1.93 | 1.59, 256^2 2.03 | 1.62, 512^2 2.73 | 2.17, 1024x512 4.35 | 3.43)
+    int rows = env_int("LBM_RESIDENT_ROWS", 0);
+    if (rows != 2 && rows != 4) rows = (ny % 2 == 0 && ny / 2 <= cus && ny >= 4) ? 2 : 4;
+    const bool shape_ok = nx % 64 == 0 && nx >= 64 && nx <= 1024 && ny % rows == 0 && ny >= 2 * rows;
     if (shape_ok && env_int("LBM_RESIDENT", other_kernel ? 0 : 1)) {
-      const int dev = c->slab[0].device;
-      int cus = 0, per_cu = 0;
-      const void* fn = (nx > 512) ? reinterpret_cast<const void*>(lbm::resident_band<1024>)
-                                  : reinterpret_cast<const void*>(lbm::resident_band<512>);
-      if (hipSetDevice(dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, nx, 0) == hipSuccess && per_cu >= 1 &&
-          ny / lbm::kResidentRows <= cus) {
+      int per_cu = 0;
+      const int joint = (rows == 4 && nx <= 512 && env_int("LBM_RESIDENT_JOINT", nx <= 256 ? 1 : 0)) ? 1 : 0;
+      if (cus > 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, resident_kernel(nx, rows, joint), nx, 0) == hipSuccess &&
+          per_cu >= 1 && ny / rows <= cus) {
         c->resident = 1;
-        c->resident_bands = ny / lbm::kResidentRows;
-        c->resident_joint = (nx <= 512 && env_int("LBM_RESIDENT_JOINT", nx <= 256 ? 1 : 0)) ? 1 : 0;
+        c->resident_rows = rows;
+        c->resident_bands = ny / rows;
+        c->resident_joint = joint;
         // a launch costs about 35 us before its first step (lattice into registers, back out, reduce); measured wall
         // time of one lbm_run(n) + sync, per-pass kernels | resident: 128^2 n = 64 149 | 156, n = 128 285 | 277;
         // 256^2 n = 16 66 | 69, n = 32 115 | 100; 1024^2 n = 4 63 | 63, n = 8 100 | 83 (tools/resident_crossover.py)

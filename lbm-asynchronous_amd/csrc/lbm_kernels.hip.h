@@ -1600,8 +1600,13 @@ __device__ __forceinline__ granule_vec granule_load(__amdgpu_buffer_rsrc_t rsrc,
 // the other, and two independent chains interleave (issue-bound instead of latency-bound).  Wide grids (four waves
 // per SIMD) keep the interior pair in front of the halo wait: their SIMDs are busy anyway and the interior pair
 // hides the hop.
-template <int MAXT, bool JOINT = false>
+// ROWS: rows per band, 4 (above) or 2 -- one pair per lane, both rows seam rows: twice the workgroups and half the
+// dependent work per lane and step, for grids small enough that the chip has CUs to spare (ny / 2 <= CUs): there the
+// step is one wave's chain "hop + collisions", and the shorter chain wins although nothing hides the hop any more.
+template <int MAXT, bool JOINT = false, int ROWS = 4>
 __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
+  static_assert(ROWS == 4 || ROWS == 2, "bands of four or two rows");
+  constexpr int NE = (ROWS == 4) ? 10 : 4;  // wave-edge values per side
   const int x = threadIdx.x, lane = x & 63, wave = x >> 6, n_waves = blockDim.x >> 6;
   const int bands = gridDim.x;
   // Workgroups are dealt to the 8 XCDs round-robin (observed, not promised): consecutive bands are given to
@@ -1609,30 +1614,33 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
   // established below from the hardware's own XCC id, and the protocol is correct for any placement.
   const int b = (a.xcd_affinity && (bands & 7) == 0) ? (int)(blockIdx.x & 7) * (bands >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const long ps = a.plane_stride;
-  // wave-edge values: [parity][wave][side: 0 = lane 0's west-moving, 1 = lane 63's east-moving][10 used of 12]
+  // wave-edge values: [parity][wave][side: 0 = lane 0's west-moving, 1 = lane 63's east-moving][NE used of 12]
   __shared__ __attribute__((aligned(16))) float edge[2][MAXT / 64][2][12];
   __shared__ float wave_part[2][MAXT / 64];
   if (b == a.absent_band) return;
 
-  // ---- the band's four rows: interior pair = rows (1, 2), edge pair = rows (0, 3) ----------------------------
+  // ---- the band's rows.  ROWS = 4: interior pair ri = rows (1, 2), edge pair re = rows (0, 3); ROWS = 2: re = rows (0, 1)
+  constexpr int TOP = ROWS - 1;  // the band's last row: the .y half of the edge pair
   f2 ri[kQ], re[kQ];
   {
-    const float* base = a.src + (long)(kResidentRows * b) * a.row_pitch + x;
+    const float* base = a.src + (long)(ROWS * b) * a.row_pitch + x;
 #pragma unroll
     for (int k = 0; k < kQ; k++) {
-      ri[k] = f2{base[1 * a.row_pitch + k * ps], base[2 * a.row_pitch + k * ps]};
-      re[k] = f2{base[k * ps], base[3 * a.row_pitch + k * ps]};
+      re[k] = f2{base[k * ps], base[TOP * a.row_pitch + k * ps]};
+      if constexpr (ROWS == 4) ri[k] = f2{base[1 * a.row_pitch + k * ps], base[2 * a.row_pitch + k * ps]};
+      else ri[k] = splat2(0.f);
     }
   }
-  const unsigned char* mp = a.mask + (long)(kResidentRows * b) * a.pitch + x;
-  const unsigned blocked_i = (unsigned)mp[a.pitch] | ((unsigned)mp[2 * a.pitch] << 8);
-  const unsigned blocked_e = (unsigned)mp[0] | ((unsigned)mp[3 * a.pitch] << 8);
+  const unsigned char* mp = a.mask + (long)(ROWS * b) * a.pitch + x;
+  const unsigned blocked_e = (unsigned)mp[0] | ((unsigned)mp[TOP * a.pitch] << 8);
+  unsigned blocked_i = 0;
+  if constexpr (ROWS == 4) blocked_i = (unsigned)mp[a.pitch] | ((unsigned)mp[2 * a.pitch] << 8);
   // accelerate_flow's row, if this band holds it: bit per cell of the pair it falls in
-  const int lid_local = a.accel_row - kResidentRows * b;
-  const unsigned lid_i = (lid_local == 1) ? 1u : (lid_local == 2 ? 2u : 0u);
-  const unsigned lid_e = (lid_local == 0) ? 1u : (lid_local == 3 ? 2u : 0u);
+  const int lid_local = a.accel_row - ROWS * b;
+  const unsigned lid_i = (ROWS == 4) ? ((lid_local == 1) ? 1u : (lid_local == 2 ? 2u : 0u)) : 0u;
+  const unsigned lid_e = (lid_local == 0) ? 1u : (lid_local == TOP ? 2u : 0u);
 
-  // seam granules: `up` carries a band's row-3 populations 2,5,6 northwards, `down` its row-0 populations 4,7,8;
+  // seam granules: `up` carries a band's top-row populations 2,5,6 northwards, `down` its row-0 populations 4,7,8;
   // byte offsets into the one buffer (32-bit: it is at most 16 MiB)
   const __amdgpu_buffer_rsrc_t grsrc = granule_rsrc(a.gran, a.gran_bytes);
   const unsigned band_bytes = 2u * (unsigned)a.nx * 16u, slot_bytes = (unsigned)a.nx * 16u;
@@ -1675,28 +1683,45 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
   }
   const int west_wave = (wave == 0) ? n_waves - 1 : wave - 1, east_wave = (wave == n_waves - 1) ? 0 : wave + 1;
 
+  // publish the edge rows of a state: step s of this launch reads what was published with its tag into its slot
+  auto publish = [&](int s) {
+    const unsigned tag = a.epoch0 + (unsigned)s + 1u;
+    const unsigned off = (unsigned)(s & 1) * slot_bytes;
+    if (north_local) granule_store_local(grsrc, my_up + off, re[2].y, re[5].y, re[6].y, tag);
+    else granule_store(grsrc, my_up + off, re[2].y, re[5].y, re[6].y, tag);
+    if (south_local) granule_store_local(grsrc, my_down + off, re[4].x, re[7].x, re[8].x, tag);
+    else granule_store(grsrc, my_down + off, re[4].x, re[7].x, re[8].x, tag);
+  };
+  if (a.n_steps > 0) publish(0);
+
   bool alive = true;
   for (int s = 0; s < a.n_steps && alive; s++) {
     const unsigned tag = a.epoch0 + (unsigned)s + 1u;
     const int slot = s & 1;
-    // ---- publish the edge rows of the current state -------------------------------------------------------
-    if (north_local) granule_store_local(grsrc, my_up + (unsigned)slot * slot_bytes, re[2].y, re[5].y, re[6].y, tag);
-    else granule_store(grsrc, my_up + (unsigned)slot * slot_bytes, re[2].y, re[5].y, re[6].y, tag);
-    if (south_local) granule_store_local(grsrc, my_down + (unsigned)slot * slot_bytes, re[4].x, re[7].x, re[8].x, tag);
-    else granule_store(grsrc, my_down + (unsigned)slot * slot_bytes, re[4].x, re[7].x, re[8].x, tag);
+    // (the edge rows of the current state were published as soon as they existed: before the loop / at the end of
+    // the previous iteration)
     // ---- wave-edge lanes through LDS ------------------------------------------------------------------------
-    // east-moving (from lane 63): 1 of rows 0..3, 5 of rows 0..2, 8 of rows 1..3; west-moving (from lane 0): 3, 6, 7
+    // ROWS = 4: east-moving (from lane 63) 1 of rows 0..3, 5 of rows 0..2, 8 of rows 1..3; west-moving (from lane 0) 3, 6, 7
+    // ROWS = 2: east-moving 1 of rows 0, 1, 5 of row 0, 8 of row 1; west-moving 3 of rows 0, 1, 6 of row 0, 7 of row 1
     if (lane == 63) {
       float* e = edge[slot][wave][1];
-      e[0] = re[1].x; e[1] = ri[1].x; e[2] = ri[1].y; e[3] = re[1].y;
-      e[4] = re[5].x; e[5] = ri[5].x; e[6] = ri[5].y; e[7] = ri[8].x;
-      e[8] = ri[8].y; e[9] = re[8].y;
+      if constexpr (ROWS == 4) {
+        e[0] = re[1].x; e[1] = ri[1].x; e[2] = ri[1].y; e[3] = re[1].y;
+        e[4] = re[5].x; e[5] = ri[5].x; e[6] = ri[5].y; e[7] = ri[8].x;
+        e[8] = ri[8].y; e[9] = re[8].y;
+      } else {
+        e[0] = re[1].x; e[1] = re[1].y; e[2] = re[5].x; e[3] = re[8].y;
+      }
     }
     if (lane == 0) {
       float* e = edge[slot][wave][0];
-      e[0] = re[3].x; e[1] = ri[3].x; e[2] = ri[3].y; e[3] = re[3].y;
-      e[4] = re[6].x; e[5] = ri[6].x; e[6] = ri[6].y; e[7] = ri[7].x;
-      e[8] = ri[7].y; e[9] = re[7].y;
+      if constexpr (ROWS == 4) {
+        e[0] = re[3].x; e[1] = ri[3].x; e[2] = ri[3].y; e[3] = re[3].y;
+        e[4] = re[6].x; e[5] = ri[6].x; e[6] = ri[6].y; e[7] = ri[7].x;
+        e[8] = ri[7].y; e[9] = re[7].y;
+      } else {
+        e[0] = re[3].x; e[1] = re[3].y; e[2] = re[6].x; e[3] = re[7].y;
+      }
     }
     __syncthreads();
     if (s > 0 && wave == 0) {
@@ -1704,24 +1729,14 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
       const float v = row16_sum_dpp((lane < n_waves) ? wave_part[slot ^ 1][lane] : 0.f);
       if (lane == 0) a.partials[(long)(s - 1) * bands + b] = v;
     }
-    float W[10], E[10];
+    float W[NE], E[NE];
     {
       const float* w = edge[slot][west_wave][1];
       const float* e = edge[slot][east_wave][0];
 #pragma unroll
-      for (int j = 0; j < 10; j++) { W[j] = w[j]; E[j] = e[j]; }
+      for (int j = 0; j < NE; j++) { W[j] = w[j]; E[j] = e[j]; }
     }
-    // shifted populations (the value each cell receives from its west / east neighbour), by source row
-    const float s1_0 = shift_from_west(re[1].x, W[0]), s1_1 = shift_from_west(ri[1].x, W[1]);
-    const float s1_2 = shift_from_west(ri[1].y, W[2]), s1_3 = shift_from_west(re[1].y, W[3]);
-    const float s5_0 = shift_from_west(re[5].x, W[4]), s5_1 = shift_from_west(ri[5].x, W[5]), s5_2 = shift_from_west(ri[5].y, W[6]);
-    const float s8_1 = shift_from_west(ri[8].x, W[7]), s8_2 = shift_from_west(ri[8].y, W[8]), s8_3 = shift_from_west(re[8].y, W[9]);
-    const float s3_0 = shift_from_east(re[3].x, E[0]), s3_1 = shift_from_east(ri[3].x, E[1]);
-    const float s3_2 = shift_from_east(ri[3].y, E[2]), s3_3 = shift_from_east(re[3].y, E[3]);
-    const float s6_0 = shift_from_east(re[6].x, E[4]), s6_1 = shift_from_east(ri[6].x, E[5]), s6_2 = shift_from_east(ri[6].y, E[6]);
-    const float s7_1 = shift_from_east(ri[7].x, E[7]), s7_2 = shift_from_east(ri[7].y, E[8]), s7_3 = shift_from_east(re[7].y, E[9]);
-
-    // ---- the halo granules are asked for NOW, before the interior pair is relaxed: when the neighbours are not late
+    // ---- the halo granules are asked for NOW, before anything else is computed: when the neighbours are not late
     // (the usual case: their edge rows were published about when ours were) the answer is there by the time the
     // interior pair is done, and the round trip of the load is hidden behind it
     const unsigned gs = from_south + (unsigned)slot * slot_bytes, gn = from_north + (unsigned)slot * slot_bytes;
@@ -1734,17 +1749,43 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
     granule_vec ss = granule_load(grsrc, gs + x_side);
     granule_vec sn = granule_load(grsrc, gn + x_side);
 
-    // ---- interior pair: rows 1 and 2 pull from rows 0..3 of the band only -------------------------------------
     const bool accel = (s + 1 < a.n_steps) || a.accel_last;
-    f2 ti[kQ] = {ri[0], f2{s1_1, s1_2}, f2{re[2].x, ri[2].x}, f2{s3_1, s3_2}, f2{ri[4].y, re[4].y},
-                 f2{s5_0, s5_1}, f2{s6_0, s6_1}, f2{s7_2, s7_3}, f2{s8_2, s8_3}};
-    // what rows 0 and 3 pull from inside the band (kept before the interior pair is overwritten)
-    const float t4_0 = ri[4].x, t2_3 = ri[2].y;
+    // shifted populations (the value each cell receives from its west / east neighbour) and the streamed inputs of
+    // the pair(s), as far as they come from inside the band
+    f2 ti[kQ], te[kQ];
+    if constexpr (ROWS == 4) {
+      const float s1_0 = shift_from_west(re[1].x, W[0]), s1_1 = shift_from_west(ri[1].x, W[1]);
+      const float s1_2 = shift_from_west(ri[1].y, W[2]), s1_3 = shift_from_west(re[1].y, W[3]);
+      const float s5_0 = shift_from_west(re[5].x, W[4]), s5_1 = shift_from_west(ri[5].x, W[5]), s5_2 = shift_from_west(ri[5].y, W[6]);
+      const float s8_1 = shift_from_west(ri[8].x, W[7]), s8_2 = shift_from_west(ri[8].y, W[8]), s8_3 = shift_from_west(re[8].y, W[9]);
+      const float s3_0 = shift_from_east(re[3].x, E[0]), s3_1 = shift_from_east(ri[3].x, E[1]);
+      const float s3_2 = shift_from_east(ri[3].y, E[2]), s3_3 = shift_from_east(re[3].y, E[3]);
+      const float s6_0 = shift_from_east(re[6].x, E[4]), s6_1 = shift_from_east(ri[6].x, E[5]), s6_2 = shift_from_east(ri[6].y, E[6]);
+      const float s7_1 = shift_from_east(ri[7].x, E[7]), s7_2 = shift_from_east(ri[7].y, E[8]), s7_3 = shift_from_east(re[7].y, E[9]);
+      // interior pair: rows 1 and 2 pull from rows 0..3 of the band only
+      ti[0] = ri[0];               ti[1] = f2{s1_1, s1_2};      ti[2] = f2{re[2].x, ri[2].x};
+      ti[3] = f2{s3_1, s3_2};      ti[4] = f2{ri[4].y, re[4].y}; ti[5] = f2{s5_0, s5_1};
+      ti[6] = f2{s6_0, s6_1};      ti[7] = f2{s7_2, s7_3};      ti[8] = f2{s8_2, s8_3};
+      // edge pair: rows 0 and 3; the halves that come from the neighbouring bands are filled in below
+      te[0] = re[0];               te[1] = f2{s1_0, s1_3};      te[2] = f2{0.f, ri[2].y};
+      te[3] = f2{s3_0, s3_3};      te[4] = f2{ri[4].x, 0.f};     te[5] = f2{0.f, s5_2};
+      te[6] = f2{0.f, s6_2};       te[7] = f2{s7_1, 0.f};       te[8] = f2{s8_1, 0.f};
+    } else {
+      const float s1_0 = shift_from_west(re[1].x, W[0]), s1_1 = shift_from_west(re[1].y, W[1]);
+      const float s5_0 = shift_from_west(re[5].x, W[2]), s8_1 = shift_from_west(re[8].y, W[3]);
+      const float s3_0 = shift_from_east(re[3].x, E[0]), s3_1 = shift_from_east(re[3].y, E[1]);
+      const float s6_0 = shift_from_east(re[6].x, E[2]), s7_1 = shift_from_east(re[7].y, E[3]);
+      te[0] = re[0];               te[1] = f2{s1_0, s1_1};      te[2] = f2{0.f, re[2].x};
+      te[3] = f2{s3_0, s3_1};      te[4] = f2{re[4].y, 0.f};     te[5] = f2{0.f, s5_0};
+      te[6] = f2{0.f, s6_0};       te[7] = f2{s7_1, 0.f};       te[8] = f2{s8_1, 0.f};
+#pragma unroll
+      for (int k = 0; k < kQ; k++) ti[k] = splat2(0.f);
+    }
     f2 ni[kQ];
     float sum = 0.f;
-    if constexpr (!JOINT) sum = relax_pair_rows(ti, blocked_i, accel ? lid_i : 0u, a.omega, a.a1, a.a2, ni);
+    if constexpr (ROWS == 4 && !JOINT) sum = relax_pair_rows(ti, blocked_i, accel ? lid_i : 0u, a.omega, a.a1, a.a2, ni);
 
-    // ---- edge pair: rows 0 and 3 also pull from the neighbouring bands ----------------------------------------
+    // ---- edge pair: rows 0 and TOP also pull from the neighbouring bands --------------------------------------
     {
       long long t_start = 0;
       for (unsigned spins = 0;; spins++) {
@@ -1777,20 +1818,24 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
         sn = granule_load(grsrc, gn + x_side);
       }
     }
-    // south: {2, 5, 6} of its row 3; north: {4, 7, 8} of its row 0; 5 and 8 come from the west column, 6 and 7 from the east
+    // south: {2, 5, 6} of its top row; north: {4, 7, 8} of its row 0; 5 and 8 come from the west column, 6 and 7 from the east
     const float side_s = __uint_as_float((unsigned)(first ? ss.y : ss.z)), side_n = __uint_as_float((unsigned)(first ? sn.z : sn.y));
-    const float h2 = __uint_as_float((unsigned)cs.x), h4 = __uint_as_float((unsigned)cn.x);
-    const float h5 = shift_from_west(__uint_as_float((unsigned)cs.y), side_s);
-    const float h6 = shift_from_east(__uint_as_float((unsigned)cs.z), side_s);
-    const float h7 = shift_from_east(__uint_as_float((unsigned)cn.y), side_n);
-    const float h8 = shift_from_west(__uint_as_float((unsigned)cn.z), side_n);
-    f2 te[kQ] = {re[0], f2{s1_0, s1_3}, f2{h2, t2_3}, f2{s3_0, s3_3}, f2{t4_0, h4},
-                 f2{h5, s5_2}, f2{h6, s6_2}, f2{s7_1, h7}, f2{s8_1, h8}};
+    te[2].x = __uint_as_float((unsigned)cs.x);
+    te[4].y = __uint_as_float((unsigned)cn.x);
+    te[5].x = shift_from_west(__uint_as_float((unsigned)cs.y), side_s);
+    te[6].x = shift_from_east(__uint_as_float((unsigned)cs.z), side_s);
+    te[7].y = shift_from_east(__uint_as_float((unsigned)cn.y), side_n);
+    te[8].y = shift_from_west(__uint_as_float((unsigned)cn.z), side_n);
     f2 ne[kQ];
-    if constexpr (JOINT) sum = relax_two_pairs_rows(ti, te, blocked_i, blocked_e, accel ? lid_i : 0u, accel ? lid_e : 0u, a.omega, a.a1, a.a2, ni, ne);
+    if constexpr (ROWS == 4 && JOINT) sum = relax_two_pairs_rows(ti, te, blocked_i, blocked_e, accel ? lid_i : 0u, accel ? lid_e : 0u, a.omega, a.a1, a.a2, ni, ne);
     else sum += relax_pair_rows(te, blocked_e, accel ? lid_e : 0u, a.omega, a.a1, a.a2, ne);
 #pragma unroll
-    for (int k = 0; k < kQ; k++) { ri[k] = ni[k]; re[k] = ne[k]; }
+    for (int k = 0; k < kQ; k++) {
+      re[k] = ne[k];
+      if constexpr (ROWS == 4) ri[k] = ni[k];
+    }
+    // the neighbours wait for exactly these rows: out they go, before anything else
+    if (s + 1 < a.n_steps && alive) publish(s + 1);
     // blocked cells report 0; sum over the wave, one partial per wave into LDS (summed after the next barrier)
     const float tot = wave_sum_dpp(sum);
     if (lane == 63) wave_part[slot][wave] = tot;
@@ -1803,13 +1848,15 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
     const float v = row16_sum_dpp((lane < n_waves) ? wave_part[(a.n_steps - 1) & 1][lane] : 0.f);
     if (lane == 0) a.partials[(long)(a.n_steps - 1) * bands + b] = v;
   }
-  float* out = a.dst + (long)(kResidentRows * b) * a.row_pitch + x;
+  float* out = a.dst + (long)(ROWS * b) * a.row_pitch + x;
 #pragma unroll
   for (int k = 0; k < kQ; k++) {
     out[k * ps] = re[k].x;
-    out[1 * a.row_pitch + k * ps] = ri[k].x;
-    out[2 * a.row_pitch + k * ps] = ri[k].y;
-    out[3 * a.row_pitch + k * ps] = re[k].y;
+    out[TOP * a.row_pitch + k * ps] = re[k].y;
+    if constexpr (ROWS == 4) {
+      out[1 * a.row_pitch + k * ps] = ri[k].x;
+      out[2 * a.row_pitch + k * ps] = ri[k].y;
+    }
   }
 }
 

@@ -43,10 +43,13 @@ def test_resident_reference_datasets_bitwise(lbm, oracle, datasets, monkeypatch,
                                        (256, 64, {"LBM_RESIDENT_JOINT": "0"}), (320, 8, {}), (320, 24, {"LBM_RESIDENT_JOINT": "1"}),
                                        (512, 64, {}), (512, 32, {"LBM_RESIDENT_JOINT": "1"}), (704, 20, {}), (1024, 64, {}),
                                        (1024, 1024, {}), (960, 36, {}), (1024, 128, {"LBM_RESIDENT_XCD": "0"}),
-                                       (128, 64, {"LBM_RESIDENT_XCD": "0"}), (192, 36, {})])
+                                       (128, 64, {"LBM_RESIDENT_XCD": "0"}), (192, 36, {}),
+                                       (128, 128, {"LBM_RESIDENT_ROWS": "4"}), (256, 256, {"LBM_RESIDENT_ROWS": "2"}),
+                                       (64, 6, {}), (320, 30, {}), (512, 512, {"LBM_RESIDENT_ROWS": "2"}),
+                                       (1024, 512, {"LBM_RESIDENT_ROWS": "2"}), (448, 250, {"LBM_RESIDENT_ROWS": "2", "LBM_RESIDENT_XCD": "0"})])
 def test_resident_random_lattices_bitwise(lbm, oracle, monkeypatch, nx, ny, env):
     """Random lattices with random obstacles (also on the seam rows and at the wave edges), both periodic wraps live,
-    widths of 1 to 16 waves -- full and partly filled workgroups --, 2 to 256 bands; every call resident.  Both orders
+    widths of 1 to 16 waves -- full and partly filled workgroups --, 2 to 256 bands of four or two rows; every call resident.  Both orders
     of a step (interior pair before the halo wait / both pairs together behind it), seams kept in an XCD's L2 where
     both bands run on it and written through everywhere (band counts that are and are not multiples of 8)."""
     monkeypatch.setenv("LBM_RESIDENT_MIN_STEPS", "1")
@@ -107,7 +110,9 @@ def test_resident_policy(lbm, monkeypatch):
             for k in env:
                 monkeypatch.delenv(k)
     assert resident(128, 128) and resident(1024, 1024) and resident(64, 8) and resident(512, 512)
-    assert not resident(100, 128) and not resident(2048, 64) and not resident(128, 130) and not resident(128, 4)
+    assert resident(128, 130) and resident(128, 4)     # bands of two rows where the chip has CUs to spare
+    assert not resident(100, 128) and not resident(2048, 64) and not resident(128, 131) and not resident(128, 2)
+    assert not resident(1024, 1022)                    # 1024 wide: four-row bands only
     assert not resident(1024, 2048)                    # 512 bands: more than the device has CUs
     assert not resident(128, 128, LBM_FUSE2="1") and not resident(128, 128, LBM_TILE_STEPS="4")
     assert resident(128, 128, LBM_FUSE2="1", LBM_RESIDENT="1") and not resident(128, 128, LBM_RESIDENT="0")
