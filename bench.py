@@ -22,6 +22,10 @@ itself, as a CHILD process, before torch or HIP is touched in this process (neve
 single JSON line and exit status, and kills the child's process group if it outlives LBM_BENCH_LAUNCH_TIMEOUT
 (default 1500 s) -- then it exits non-zero.  Started by torch.distributed.run (WORLD_SIZE set) it is a rank.
 LBM_BENCH_SELF_LAUNCH=1 takes the child path for --gpus 1 too (rehearsal of the multi-GPU launch on one GPU).
+LBM_BENCH_REHEARSAL=hosted runs N > 1 ranks on however few GPUs there are: the ranks share devices, their halo rows
+travel through the host over gloo (lbm_create_rank_hosted_tiled) instead of RCCL -- every line of the multi-rank path of
+this file (launch, agreement on step counts, max-over-ranks timing, the bitwise self-check, exit statuses) except the
+RCCL transport itself; its numbers mean nothing and the line says so.
 
 Rank 0 prints ONE JSON line; see the task contract for its keys.  `rccl` in it says which RCCL the engine bound
 (library path, version) and how many ranks its communicator counts -- "did RCCL see N ranks, and which RCCL".  Roofline block: `achieved` is the
@@ -307,7 +311,10 @@ def main():
     if n_dev < 1:
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    if local_world > n_dev or local_rank >= n_dev:
+    rehearsal = os.environ.get("LBM_BENCH_REHEARSAL") == "hosted" and world > 1
+    if rehearsal:
+        local_rank = local_rank % n_dev          # ranks share devices; halos through the host
+    if (local_world > n_dev or local_rank >= n_dev) and not rehearsal:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {local_world} devices on this node, {n_dev} visible "
                          f"(rank {rank})\n")
         sys.exit(3)
@@ -320,12 +327,27 @@ def main():
     use_rank_api = world > 1 or os.environ.get("LBM_BENCH_RANK_API") == "1"
     if use_rank_api and "MASTER_ADDR" not in os.environ:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
-    if use_rank_api:
+    if use_rank_api and rehearsal:
+        dist.init_process_group(backend="gloo")
+    elif use_rank_api:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    red_dev = "cpu" if rehearsal else "cuda"     # where the harness's own reductions live
+
+    def host_exchange(plan, bufs):               # the four messages of a pass over gloo (rehearsal only)
+        ops = [dist.P2POp(dist.isend if op["is_send"] else dist.irecv, torch.from_numpy(buf), op["peer"])
+               for op, buf in zip(plan, bufs)]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+    def host_allreduce(values):
+        dist.all_reduce(torch.from_numpy(values), op=dist.ReduceOp.SUM)
 
     def make_engine(p, ob, tiled):
         if not use_rank_api:
             return lbm.Engine(p, ob, None, n_gpus=1, math=args.math, tiled=tiled)
+        if rehearsal:
+            return lbm.Engine(p, ob, None, math=args.math, rank=rank, world_size=world, device=local_rank,
+                              host_comm=(host_exchange, host_allreduce), tiled=tiled)
         uid = [lbm.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         return lbm.Engine(p, ob, None, math=args.math, rank=rank, world_size=world,
@@ -393,7 +415,10 @@ def main():
             "config": {"workload": f"D2Q9-BGK timestep loop, {r['workload']}, uniform-equilibrium start",
                        "grid": f"{nx}x{ny}", "math": args.math,
                        "timesteps_per_memory_pass": spl,
-                       "decomposition": (f"{world} row slab(s), one process per GPU, RCCL halo send/recv" if world > 1
+                       "decomposition": (f"REHEARSAL: {world} ranks sharing {n_dev} device(s), halo rows through the host over gloo "
+                                         f"(lbm_create_rank_hosted_tiled) -- exercises this file's multi-rank path, measures nothing"
+                                         if rehearsal else
+                                         f"{world} row slab(s), one process per GPU, RCCL halo send/recv" if world > 1
                                          else ("one rank through the rank pipeline: halo rows by RCCL self-exchange, "
                                                "interior / boundary split" if use_rank_api and os.environ.get("LBM_FORCE_HALO") == "1"
                                                else ("one rank through the rank API (communicator of one), periodic in-kernel"
@@ -403,9 +428,10 @@ def main():
                        "prewarm_steps_untimed": r["prewarm_steps"], "prewarm_target_s": prewarm_s},
             "roofline": roof,
             "results_finite": r["finite"],
-            "rccl": dict(r.get("rccl") or {}, torch_backend=("nccl (torch.distributed barrier / reductions of the "
-                                                             "bench harness)" if use_rank_api else None),
-                         note=("the engine's halo exchange: RCCL bound at first use -- LBM_RCCL_LIB, else the librccl "
+            "rccl": dict(r.get("rccl") or {}, torch_backend=(("gloo (rehearsal: no RCCL anywhere in this run)" if rehearsal else
+                                                              "nccl (torch.distributed barrier / reductions of the bench harness)")
+                                                             if use_rank_api else None),
+                         note=("REHEARSAL: halo rows through the host over gloo, the engine holds no communicator" if rehearsal else "the engine's halo exchange: RCCL bound at first use -- LBM_RCCL_LIB, else the librccl "
                                "already in the process (torch's here), else /opt/rocm/lib; nranks = ncclCommCount of "
                                "the engine's communicator" if (r.get("rccl") or {}).get("loaded") else
                                "single slab: no communicator, RCCL not loaded by the engine")),
@@ -450,8 +476,9 @@ def main():
         mine = eng.final_state()
         forced = os.environ.pop("LBM_FORCE_HALO", None)     # the reference run is a plain periodic slab
         try:
-            with lbm.Engine(p, ob, None, math=args.math, rank=0, world_size=1,
-                            unique_id=lbm.rccl_unique_id(), device=local_rank, tiled=tiled) as ref:
+            with (lbm.Engine(p, ob, None, n_gpus=1, math=args.math, tiled=tiled) if rehearsal else
+                  lbm.Engine(p, ob, None, math=args.math, rank=0, world_size=1,
+                             unique_id=lbm.rccl_unique_id(), device=local_rank, tiled=tiled)) as ref:
                 ref.run(total)
                 ref_av = ref.av_vels(total)
                 whole = ref.final_state()
@@ -461,7 +488,7 @@ def main():
         rows = slice(info["row_first"], info["row_first"] + info["row_count"])
         same = all(np.array_equal(mine[k].view(np.uint32), whole[k][rows].view(np.uint32)) for k in mine)
         rel = float(np.max(np.abs(av.astype(np.float64) - ref_av) / np.abs(ref_av)))
-        t = torch.tensor([0.0 if same else 1.0, rel], dtype=torch.float64, device="cuda")
+        t = torch.tensor([0.0 if same else 1.0, rel], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         seen = main_result.get("rccl") or eng.rccl_info()
         check.update({"fields_bitwise_equal_to_single_gpu_run": bool(t[0] == 0.0),
@@ -490,7 +517,7 @@ def main():
         def agree(v):   # every rank must run the same number of steps: take rank 0's view
             if not use_rank_api:
                 return v
-            t = torch.tensor([float(v)], dtype=torch.float64, device="cuda")
+            t = torch.tensor([float(v)], dtype=torch.float64, device=red_dev)
             dist.broadcast(t, src=0)
             return float(t[0])
 
@@ -527,7 +554,7 @@ def main():
             fence()
             elapsed = time.perf_counter() - t0
             if use_rank_api:
-                t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+                t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=red_dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 elapsed, kernel_ms = float(t[0]), float(t[1])
             runs.append((elapsed, kernel_ms))
@@ -541,7 +568,7 @@ def main():
             if use_rank_api:
                 # every rank's view of the ring: the record must show that RCCL saw `world` ranks on all of them
                 t = torch.tensor([float(rc_info["nranks"]), -float(rc_info["nranks"]), float(rc_info["version"])],
-                                 dtype=torch.float64, device="cuda")
+                                 dtype=torch.float64, device=red_dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 rc_info["nranks_min_over_ranks"] = int(-t[1])
                 rc_info["nranks_max_over_ranks"] = int(t[0])

@@ -53,6 +53,25 @@ def test_bench_oversubscribed_launch_fails_fast(lbm):
     assert secs < 180
 
 
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_bench_multi_rank_path_rehearsed_on_one_gpu(ranks):
+    """`python bench.py --gpus N` with N ranks sharing the one GPU and their halo rows travelling through the host
+    (LBM_BENCH_REHEARSAL=hosted): the launch by bench.py itself, the agreement of the ranks on step counts, the
+    max-over-ranks timing, the bitwise self-check against a single-GPU run and the exit status -- every line of the
+    multi-rank path of bench.py except the RCCL transport -- run before the first real multi-GPU node sees them."""
+    out, _ = run_bench(["--gpus", str(ranks), "--steps", "8", "--warmup", "4", "--grid", "2048x1536"],
+                       {"LBM_BENCH_REHEARSAL": "hosted"}, 600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == ranks and line["results_finite"]
+    assert "REHEARSAL" in line["config"]["decomposition"]
+    chk = line["multi_gpu_check"]
+    assert chk["fields_bitwise_equal_to_single_gpu_run"] is True and chk["ranks_checked"] == ranks, chk
+    assert chk["av_vels_max_rel_diff"] < 1e-4
+
+
 @pytest.mark.parametrize("torch_first,forced", [(False, None), (True, None), (True, "/opt/rocm/lib/librccl.so.1")])
 def test_rccl_self_exchange_under_both_libraries(torch_first, forced):
     """The engine binds the librccl already in the process (torch's bundled one when torch was imported first -- the
