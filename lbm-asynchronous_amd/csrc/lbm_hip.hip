@@ -354,7 +354,7 @@ struct lbm_ctx {
   GraphBuilder* builder = nullptr;  // non-null while a chunk is being built: launches become graph nodes
   int resident = 0;                 // single periodic slab that fits the chip's registers: lbm_run calls of at least
   int resident_min_steps = 16;      // ... this many timesteps run as launches of the resident kernel (lbm::resident_band)
-  int resident_bands = 0;           // its workgroups (bands of kResidentRows rows)
+  int resident_bands = 0;           // its workgroups (bands of resident_rows rows)
   int resident_joint = 0;           // narrow grids: both pairs of a lane relaxed as one block behind the halo wait
   int resident_rows = 4;            // rows per band: 4, or 2 where the chip has CUs to spare (one pair per lane)
   long long resident_timeout = 0;   // bound of one halo wait, wall-clock ticks

@@ -1456,7 +1456,8 @@ __global__ __launch_bounds__(THREADS) void step_tile(const TileArgs a) {
 //
 // Geometry: workgroup b owns the band of rows [4b, 4b+4), the full width; thread x owns column x of the band: four
 // cells, kept as two PAIRS for the packed arithmetic -- the interior pair (rows 1, 2) and the edge pair (rows 0, 3).
-// 36 VGPRs of state per lane; a 1024 x 1024 lattice is 256 workgroups of 1024 threads, one per CU.
+// 36 VGPRs of state per lane; a 1024 x 1024 lattice is 256 workgroups of 1024 threads, one per CU.  (ROWS = 2: bands
+// of two rows, one pair per lane, where the chip has CUs to spare.)
 //   streaming in y inside the band : register renaming (free)
 //   streaming in x                 : DPP wave_shr / wave_shl; lane 0 / 63 of a wave take the neighbouring wave's edge
 //                                    lane from LDS (one s_barrier per timestep, two LDS slots by parity)
@@ -1499,7 +1500,6 @@ struct ResidentArgs {
   int xcd_affinity;           // 1: seams inside one XCD use L2-resident stores (see resident_band); 0: sc1 everywhere
   int absent_band;            // tests: this band's workgroup returns at once, as if it had never been scheduled (-1: none)
 };
-constexpr int kResidentRows = 4;
 constexpr int kResidentTimeout = 1;
 
 // per-cell lid flags (bit 0: cell .x, bit 1: cell .y): the pair's two cells lie in different rows here
