@@ -1794,11 +1794,12 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
         c->resident_rows = rows;
         c->resident_bands = ny / rows;
         c->resident_joint = joint;
-        // a launch costs about 35 us before its first step (lattice into registers, back out, reduce); measured wall
-        // time of one lbm_run(n) + sync, per-pass kernels | resident: 128^2 n = 64 149 | 156, n = 128 285 | 277;
-        // 256^2 n = 16 66 | 69, n = 32 115 | 100; 1024^2 n = 4 63 | 63, n = 8 100 | 83 (tools/resident_crossover.py)
+        // a launch costs about 20 us before its first step (lattice into registers, back out, reduce, status copy);
+        // measured wall time of one lbm_run(n) + sync, per-pass kernels | resident (tools/resident_crossover.py):
+        // 128^2 n = 4 24.5 | 27.0, n = 8 32.9 | 32.4, n = 16 50.0 | 44.4; 256^2 n = 4 28.8 | 28.4, n = 8 41.0 | 35.4;
+        // 1024^2 n = 4 59.8 | 50.4, n = 8 96.2 | 69.1
         const long cells = (long)nx * ny;
-        c->resident_min_steps = env_int("LBM_RESIDENT_MIN_STEPS", cells >= 512L * 1024 ? 8 : (cells >= 48L * 1024 ? 32 : 128));
+        c->resident_min_steps = env_int("LBM_RESIDENT_MIN_STEPS", cells >= 48L * 1024 ? 4 : 8);
         if (c->resident_min_steps < 1) c->resident_min_steps = 1;
         c->resident_timeout = (long long)env_int("LBM_RESIDENT_TIMEOUT_MS", 2000) * 100000LL;  // wall_clock64(): 100 MHz
       }

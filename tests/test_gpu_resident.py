@@ -1,6 +1,6 @@
 """The resident-lattice kernel (lbm::resident_band): one launch per lbm_run call, the lattice in registers, seam rows
 between 4-row bands through tagged L2 granules.  Default for single periodic slabs of at most 1024 x 4*CUs cells and
-calls long enough to pay for a launch (8 steps at 1024^2, 128 at 128^2) -- i.e. for the reference's own data sets.  Lattice bit-identical to the oracle."""
+calls long enough to pay for a launch (4 steps; 8 below 48 Ki cells) -- i.e. for the reference's own data sets.  Lattice bit-identical to the oracle."""
 import numpy as np
 import pytest
 
@@ -26,8 +26,7 @@ def run_resident(lbm, oracle, p, ob, cells, calls, math="exact"):
 @pytest.mark.parametrize("name,calls", [("128x128", [37]), ("128x128", [16, 1, 40, 3, 17]), ("128x256", [300]),
                                         ("256x256", [50]), ("1024x1024", [24])])
 def test_resident_reference_datasets_bitwise(lbm, oracle, datasets, monkeypatch, name, calls):
-    """The reference's data sets: calls of >= 16 steps run resident here (the default threshold grows as the grid
-    shrinks: 8 / 32 / 128 steps), shorter ones launch per pass; the lid row, the walls and the periodic seam between
+    """The reference's data sets: calls of >= 16 steps run resident here (the default threshold is 4 steps, 8 below 48 Ki cells), shorter ones launch per pass; the lid row, the walls and the periodic seam between
     the last and the first band are all live."""
     monkeypatch.setenv("LBM_RESIDENT_MIN_STEPS", "16")
     p, ob = datasets(name)
