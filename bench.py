@@ -368,17 +368,20 @@ def main():
         # `spl` timesteps: it must read the lattice once and write it once -- 72 B per cell whatever spl is.
         rows_per_rank = -(-ny // world)
         compulsory_bytes = BYTES_PER_UPDATE * nx * rows_per_rank
-        launch_ms = kernel_ms * spl
-        achieved = compulsory_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
         pmc = pmc_record(nx, ny, args.math, info, args.steps) if world == 1 else None
         if runs_resident(info, args.steps):
             kernel_name = "lbm::resident_band"
-            spl = args.steps            # one launch advances the whole timed region
+            spl = min(args.steps, info["resident_steps"])   # one launch advances the whole timed region: the lattice is
+            # read and written once per LAUNCH, so the HBM fraction below is tiny by construction -- the kernel's bound
+            # is instruction issue (roofline.limiter), not memory
         elif info["lane_cells"] > 0:      # a stream kernel: several timesteps per pass
-            kernel_name = ("lbm::stepk_pk" if args.math == "exact" else
+            packed = os.environ.get("LBM_PACKED", "1") != "0"     # the packed kernels serve both math modes
+            kernel_name = ("lbm::stepk_pk" if packed else
                            ("lbm::stepk_stream" if info["lane_cells"] == 4 else "lbm::step2_stream"))
         else:
             kernel_name = "lbm::step_vec4" if spl == 1 else "lbm::step_tile"
+        launch_ms = kernel_ms * spl
+        achieved = compulsory_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc.get("traffic_bytes_per_launch") if pmc else None,
