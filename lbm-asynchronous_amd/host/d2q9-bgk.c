@@ -66,6 +66,21 @@ int main(int argc, char* argv[])
     obstacles = lbm_read_obstacles(obstaclefile, &params);
     ctx = lbm_create(&params, obstacles, NULL, n_gpus, math_mode);
   }
+  if (n_gpus > 1) {
+    /* the MPI programs announce their ranks ("Process %d of %d started.", MPI/d2q9-bgk.c:151): here, what the halo
+       transport is -- which RCCL, and how many ranks its communicators count */
+    lbm_rccl_status st;
+    lbm_info info;
+    if (lbm_rccl_info(ctx, &st) == LBM_SUCCESS && lbm_get_info(ctx, &info) == LBM_SUCCESS) {
+      if (st.n_comms > 0)
+        fprintf(stderr, "%d row slabs on %d device(s): RCCL %d.%d.%d (%s), %d communicators of %d ranks\n", info.n_slabs,
+                lbm_device_count() < n_gpus ? lbm_device_count() : n_gpus, st.version / 10000, st.version / 100 % 100,
+                st.version % 100, st.library, st.n_comms, st.nranks);
+      else
+        fprintf(stderr, "%d row slabs on %d device(s): halo rows by device copies\n", info.n_slabs,
+                lbm_device_count() < n_gpus ? lbm_device_count() : n_gpus);
+    }
+  }
   lbm_sync(ctx);
   const double init_toc = wall_seconds();
 
