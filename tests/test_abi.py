@@ -141,3 +141,15 @@ def test_plan_halo_depth_follows_the_kernel_policy(lbm, monkeypatch):
     monkeypatch.delenv("LBM_PACKED")
     monkeypatch.setenv("LBM_PASS_STEPS", "2")
     assert lbm.plan_halo_depth(big, 8) == 2
+
+
+def test_rccl_is_bound_at_first_use_and_named(lbm):
+    """RCCL is not a link-time dependency of the engine: liblbm_hip.so carries no DT_NEEDED entry for it, and
+    lbm_rccl_info(NULL) binds it by the stated rule (here, a process without torch: ROCm's own) and says which file and
+    version it was -- no device needed."""
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", lbm.LIB_PATH], capture_output=True, text=True).stdout
+    assert "librccl" not in needed
+    info = lbm.rccl_info()
+    assert info["loaded"] and info["version"] >= 22000 and info["n_comms"] == 0 and info["nranks"] == 0
+    assert os.path.exists(info["library"]) and "librccl" in info["library"]
