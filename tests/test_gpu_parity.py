@@ -78,8 +78,14 @@ def test_exact_bitwise_ragged_widths(lbm, oracle, nx, ny):
     np.testing.assert_allclose(got_av, ref_av, rtol=AV_RTOL, atol=1e-12)
 
 
-def test_av_vels_against_float64_resummation(lbm, oracle, datasets):
-    """Tight av_vels check: per-cell |u| is bit-identical, so only the summation differs."""
+@pytest.mark.parametrize("resident,rtol", [("0", 1e-6), ("1", 1e-4)])
+def test_av_vels_against_float64_resummation(lbm, oracle, datasets, monkeypatch, resident, rtol):
+    """Tight av_vels check.  The LDS-tile and one-step kernels take |u| from the relaxed populations exactly as
+    av_velocity() does (SerialCode/d2q9-bgk.c:426-450): per-cell |u| is bit-identical, only the summation differs
+    (1e-6).  The resident and the multi-step stream kernels take it from the pre-collision moments with the native
+    v_sqrt_f32 (BGK conserves density and momentum): measured 4.3e-5 relative in the first steps of this run, where
+    |u| ~ 1e-5, three orders of magnitude inside check.py's 1 % -- av_vels is tolerance-only there."""
+    monkeypatch.setenv("LBM_RESIDENT", resident)
     p, ob = datasets("128x256")
     ref = oracle.init_cells(p)
     steps = 40
@@ -91,7 +97,7 @@ def test_av_vels_against_float64_resummation(lbm, oracle, datasets):
     with lbm.Engine(p, ob, oracle.init_cells(p)) as eng:
         eng.run(steps)
         got = eng.av_vels(steps)
-    np.testing.assert_allclose(got, np.array(want, dtype=np.float32), rtol=1e-6, atol=0)
+    np.testing.assert_allclose(got, np.array(want, dtype=np.float32), rtol=rtol, atol=0)
 
 
 def test_all_blocked_and_no_blocked(lbm, oracle):
@@ -107,7 +113,10 @@ def test_all_blocked_and_no_blocked(lbm, oracle):
     ob[14, 5] = 0
     ref_cells, ref_av, got_cells, got_av, _ = run_both(lbm, oracle, p, ob, cells, 10)
     assert np.array_equal(ref_cells.view(np.uint32), got_cells.view(np.uint32))
-    np.testing.assert_allclose(got_av, ref_av, rtol=AV_RTOL)
+    # ONE fluid cell whose momentum cancels to rounding noise every other step (|u| ~ 2e-8 next to populations of
+    # 1e-2): the resident / stream kernels take |u| from the pre-collision moments, which differ from the relaxed
+    # cell's by that noise -- an absolute 2e-8, meaningless as a ratio
+    np.testing.assert_allclose(got_av, ref_av, rtol=AV_RTOL, atol=1e-7)
 
 
 def test_run_in_pieces_equals_one_run(lbm, oracle, datasets):
@@ -120,8 +129,10 @@ def test_run_in_pieces_equals_one_run(lbm, oracle, datasets):
         for n in (1, 2, 64, 23):
             two.run(n)
         assert np.array_equal(one.cells().view(np.uint32), two.cells().view(np.uint32))
-        # av_vels: same cells, possibly different summation order (one- vs two-step kernels)
-        np.testing.assert_allclose(one.av_vels(90), two.av_vels(90), rtol=1e-6, atol=0)
+        # av_vels: same cells, but the short calls run the LDS-tile kernel (|u| of the relaxed cell, av_velocity()'s own
+        # arithmetic) and the long ones the resident kernel (|u| from the pre-collision moments, native sqrt): up to
+        # 2.6e-5 apart in the first steps, where |u| ~ 1e-5 -- av_vels is tolerance-only
+        np.testing.assert_allclose(one.av_vels(90), two.av_vels(90), rtol=5e-5, atol=0)
 
 
 @pytest.mark.parametrize("slabs", [2, 3, 4, 8])
