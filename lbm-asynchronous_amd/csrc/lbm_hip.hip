@@ -1132,12 +1132,32 @@ int run_resident(lbm_ctx* c, int n_steps) {
     a.status = sl.res_status;
     a.timeout_ticks = c->resident_timeout;
     a.absent_band = env_int("LBM_RESIDENT_ABSENT_BAND", -1);  // tests of the give-up path
+    a.one_xcd = env_int("LBM_RESIDENT_ONE_XCD", 0) ? 1 : 0;
+#ifdef LBM_RESIDENT_PROFILE
+    static long long* prof_dev = nullptr;
+    if (!prof_dev) HIP_TRY(LBM_FAILURE, hipMalloc(&prof_dev, 1024 * 8 * sizeof(long long)));
+    a.prof = prof_dev;
+#endif
     void* args[] = {&a};
-    HIP_TRY(LBM_FAILURE, hipLaunchKernel(resident_kernel(c->p.nx, c->resident_rows, c->resident_joint), dim3(c->resident_bands),
+    HIP_TRY(LBM_FAILURE, hipLaunchKernel(resident_kernel(c->p.nx, c->resident_rows, c->resident_joint), dim3(c->resident_bands * (a.one_xcd ? 8 : 1)),
                                          dim3(c->p.nx), args, 0, sl.compute));
     hipLaunchKernelGGL(lbm::reduce_band_partials, dim3(n), dim3(64), 0, sl.compute, (const float*)sl.res_part,
                        c->resident_bands, sl.tot_u, c->steps_done + t);
     HIP_TRY(LBM_FAILURE, hipGetLastError());
+#ifdef LBM_RESIDENT_PROFILE
+    {
+      static const char* const phase[8] = {"edges->LDS", "barrier", "shifts(+interior)", "first halo answer", "further polls", "collision", "publish+sum", "extra polls (count)"};
+      std::vector<long long> h(c->resident_bands * 8);
+      HIP_TRY(LBM_FAILURE, hipStreamSynchronize(sl.compute));
+      HIP_TRY(LBM_FAILURE, hipMemcpy(h.data(), prof_dev, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+      fprintf(stderr, "resident profile %dx%d rows %d, %d steps (s_memtime ticks per step, wave 0 of each band: mean / min / max over bands)\n", c->p.nx, sl.rows, c->resident_rows, n);
+      for (int i = 0; i < 8; i++) {
+        double sum = 0, lo = 1e30, hi = 0;
+        for (int b = 0; b < c->resident_bands; b++) { const double v = (double)h[b * 8 + i] / n; sum += v; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+        fprintf(stderr, "  %-20s %9.2f %9.2f %9.2f\n", phase[i], sum / c->resident_bands, lo, hi);
+      }
+    }
+#endif
     c->cur ^= 1;
     t += n;
   }

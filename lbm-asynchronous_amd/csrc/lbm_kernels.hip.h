@@ -998,8 +998,10 @@ __device__ __forceinline__ bool relax_pair_core(const f2 (&f)[kQ], float omega, 
 // speed 0 kept, SerialCode/d2q9-bgk.c:291-298): a select per population half under ONE wave-level branch -- on the
 // reference's geometry (walls every few hundred columns) a third of all pair relaxations meet a blocked cell somewhere
 // in the wave, and the per-cell scalar path they used to take cost 13.5 % of the 8192^2 step (0.2826 vs 0.2443 ms
-// without obstacles).  The lid row is accelerated and a failed guard sends the cell through the scalar code (IEEE
-// divides): rare, per cell.  sp0 / sp1: the cells' |u| (0 for blocked cells).
+// without obstacles).  The lid row is accelerated by selects too (accelerate_select: the resident kernel's band
+// that holds the lid row sets the pace of all the others, and the scalar path cost it 2.4 x the collision time);
+// only a failed guard sends a cell through the scalar code (IEEE divides): rare, per cell.  sp0 / sp1: the cells' |u|
+// (0 for blocked cells).
 __device__ __forceinline__ void bounce_select(const f2 (&f)[kQ], bool b0, bool b1, f2 (&r)[kQ], float& sp0, float& sp1) {
   constexpr int opp[kQ] = {0, 3, 4, 1, 2, 7, 8, 5, 6};
 #pragma unroll
@@ -1010,24 +1012,42 @@ __device__ __forceinline__ void bounce_select(const f2 (&f)[kQ], bool b0, bool b
   sp0 = b0 ? 0.f : sp0;
   sp1 = b1 ? 0.f : sp1;
 }
+// accelerate_flow on the relaxed cells of a pair (SerialCode/d2q9-bgk.c:196-213), per cell where c0 / c1 says so: the
+// same three tests and six sums as accelerate(), as selects
+__device__ __forceinline__ void accelerate_select(f2 (&r)[kQ], bool c0, bool c1, float a1, float a2) {
+  const bool g0 = c0 && (r[3].x - a1) > 0.f && (r[6].x - a2) > 0.f && (r[7].x - a2) > 0.f;
+  const bool g1 = c1 && (r[3].y - a1) > 0.f && (r[6].y - a2) > 0.f && (r[7].y - a2) > 0.f;
+  constexpr int plus[3] = {1, 5, 8}, minus[3] = {3, 6, 7};
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const float a = (i == 0) ? a1 : a2;
+    const f2 up = f2{r[plus[i]].x + a, r[plus[i]].y + a}, dn = f2{r[minus[i]].x - a, r[minus[i]].y - a};
+    r[plus[i]] = f2{g0 ? up.x : r[plus[i]].x, g1 ? up.y : r[plus[i]].y};
+    r[minus[i]] = f2{g0 ? dn.x : r[minus[i]].x, g1 ? dn.y : r[minus[i]].y};
+  }
+}
+// the cells of a pair whose guard failed: the scalar code (IEEE divides), per cell -- rare
+__device__ __forceinline__ void relax_pair_guard_path(const f2 (&f)[kQ], bool b0, bool b1, float omega, f2 (&r)[kQ],
+                                                      bool want_speed, float& sp0, float& sp1) {
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    if (!(c == 0 ? b0 : b1)) {
+      float ts[kQ], rs[kQ], speed;
+#pragma unroll
+      for (int k = 0; k < kQ; k++) ts[k] = f[k][c];
+      relax_cell<0, 1>(ts, false, false, omega, 0.f, 0.f, rs, speed, want_speed);
+#pragma unroll
+      for (int k = 0; k < kQ; k++) r[k][c] = rs[k];
+      if (c == 0) sp0 = speed; else sp1 = speed;
+    }
+  }
+}
 __device__ __forceinline__ void relax_pair_fixup(const f2 (&f)[kQ], bool ok, unsigned blocked, bool lid, float omega,
                                                  float a1, float a2, f2 (&r)[kQ], bool want_speed, float& sp0, float& sp1) {
   if (!ok || lid || blocked != 0) {  // ONE branch on the way of a wave without exceptions
     const bool b0 = (blocked & 0xffu) != 0, b1 = (blocked & 0xff00u) != 0;
-    if (!ok || lid) {
-#pragma unroll
-      for (int c = 0; c < 2; c++) {
-        if (!(c == 0 ? b0 : b1)) {
-          float ts[kQ], rs[kQ], speed;
-#pragma unroll
-          for (int k = 0; k < kQ; k++) ts[k] = f[k][c];
-          relax_cell<0, 1>(ts, false, lid, omega, a1, a2, rs, speed, want_speed);
-#pragma unroll
-          for (int k = 0; k < kQ; k++) r[k][c] = rs[k];
-          if (c == 0) sp0 = speed; else sp1 = speed;
-        }
-      }
-    }
+    if (!ok) relax_pair_guard_path(f, b0, b1, omega, r, want_speed, sp0, sp1);
+    if (lid) accelerate_select(r, !b0, !b1, a1, a2);
     if (blocked != 0) bounce_select(f, b0, b1, r, sp0, sp1);
   }
 }
@@ -1499,7 +1519,21 @@ struct ResidentArgs {
   int poll_sleep;             // s_sleep argument (units of 64 clocks) between two looks at the halo granules
   int xcd_affinity;           // 1: seams inside one XCD use L2-resident stores (see resident_band); 0: sc1 everywhere
   int absent_band;            // tests: this band's workgroup returns at once, as if it had never been scheduled (-1: none)
+  int one_xcd;                // 1: the launch has 8 workgroups per band and only those dealt to the first XCD work
+#ifdef LBM_RESIDENT_PROFILE
+  long long* prof;            // tools/resident_profile.sh: [band][8] shader-clock sums of the phases of a step
+#endif
 };
+#ifdef LBM_RESIDENT_PROFILE
+__device__ __forceinline__ long long prof_clock() {
+  long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define RESIDENT_PROF(i) do { const long long now_ = prof_clock(); prof_acc[i] += now_ - prof_t; prof_t = now_; } while (0)
+#else
+#define RESIDENT_PROF(i) do { } while (0)
+#endif
 constexpr int kResidentTimeout = 1;
 
 // per-cell lid flags (bit 0: cell .x, bit 1: cell .y): the pair's two cells lie in different rows here
@@ -1507,21 +1541,8 @@ __device__ __forceinline__ void relax_pair_fixup_rows(const f2 (&f)[kQ], bool ok
                                                       float a1, float a2, f2 (&r)[kQ], float& sp0, float& sp1) {
   if (!ok || lid != 0 || blocked != 0) {
     const bool b0 = (blocked & 0xffu) != 0, b1 = (blocked & 0xff00u) != 0;
-    if (!ok || lid != 0) {
-#pragma unroll
-      for (int c = 0; c < 2; c++) {
-        const bool is_lid = ((lid >> c) & 1u) != 0;
-        if (!(c == 0 ? b0 : b1) && (!ok || is_lid)) {
-          float ts[kQ], rs[kQ], speed;
-#pragma unroll
-          for (int k = 0; k < kQ; k++) ts[k] = f[k][c];
-          relax_cell<0, 1>(ts, false, is_lid, omega, a1, a2, rs, speed, true);
-#pragma unroll
-          for (int k = 0; k < kQ; k++) r[k][c] = rs[k];
-          if (c == 0) sp0 = speed; else sp1 = speed;
-        }
-      }
-    }
+    if (!ok) relax_pair_guard_path(f, b0, b1, omega, r, true, sp0, sp1);
+    if (lid != 0) accelerate_select(r, (lid & 1u) != 0 && !b0, (lid & 2u) != 0 && !b1, a1, a2);
     if (blocked != 0) bounce_select(f, b0, b1, r, sp0, sp1);
   }
 }
@@ -1608,11 +1629,13 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
   static_assert(ROWS == 4 || ROWS == 2, "bands of four or two rows");
   constexpr int NE = (ROWS == 4) ? 10 : 4;  // wave-edge values per side
   const int x = threadIdx.x, lane = x & 63, wave = x >> 6, n_waves = blockDim.x >> 6;
-  const int bands = gridDim.x;
+  const int bands = a.one_xcd ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  if (a.one_xcd && (blockIdx.x & 7) != 0) return;
   // Workgroups are dealt to the 8 XCDs round-robin (observed, not promised): consecutive bands are given to
   // workgroups 8 apart, so that most seams join two bands on ONE XCD.  Speed only -- which seams really do is
   // established below from the hardware's own XCC id, and the protocol is correct for any placement.
-  const int b = (a.xcd_affinity && (bands & 7) == 0) ? (int)(blockIdx.x & 7) * (bands >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int b = a.one_xcd ? (int)(blockIdx.x >> 3)
+              : (a.xcd_affinity && (bands & 7) == 0) ? (int)(blockIdx.x & 7) * (bands >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const long ps = a.plane_stride;
   // wave-edge values: [parity][wave][side: 0 = lane 0's west-moving, 1 = lane 63's east-moving][NE used of 12]
   __shared__ __attribute__((aligned(16))) float edge[2][MAXT / 64][2][12];
@@ -1695,6 +1718,9 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
   if (a.n_steps > 0) publish(0);
 
   bool alive = true;
+#ifdef LBM_RESIDENT_PROFILE
+  long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t = prof_clock();
+#endif
   for (int s = 0; s < a.n_steps && alive; s++) {
     const unsigned tag = a.epoch0 + (unsigned)s + 1u;
     const int slot = s & 1;
@@ -1723,7 +1749,9 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
         e[0] = re[3].x; e[1] = re[3].y; e[2] = re[6].x; e[3] = re[7].y;
       }
     }
+    RESIDENT_PROF(0);  // wave-edge values into LDS
     __syncthreads();
+    RESIDENT_PROF(1);  // barrier
     if (s > 0 && wave == 0) {
       // the per-wave sums of the previous step, written before this barrier: one partial per band and step
       const float v = row16_sum_dpp((lane < n_waves) ? wave_part[slot ^ 1][lane] : 0.f);
@@ -1785,11 +1813,16 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
     float sum = 0.f;
     if constexpr (ROWS == 4 && !JOINT) sum = relax_pair_rows(ti, blocked_i, accel ? lid_i : 0u, a.omega, a.a1, a.a2, ni);
 
+    RESIDENT_PROF(2);  // partial of the previous step, LDS edges read, shifts, halo loads issued, interior pair (ROWS 4, !JOINT)
     // ---- edge pair: rows 0 and TOP also pull from the neighbouring bands --------------------------------------
     {
       long long t_start = 0;
       for (unsigned spins = 0;; spins++) {
         const bool ok = ((unsigned)cs.w == tag) & ((unsigned)cn.w == tag) & ((unsigned)ss.w == tag) & ((unsigned)sn.w == tag);
+#ifdef LBM_RESIDENT_PROFILE
+        if (spins == 0) RESIDENT_PROF(3);  // first answer of the halo loads
+        else prof_acc[7] += 1;
+#endif
         if (__all(ok)) break;
         // not there yet: every so often look at the clock and at what the other workgroups say (wave-uniform)
         if ((spins & 63u) == 63u) {
@@ -1818,6 +1851,7 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
         sn = granule_load(grsrc, gn + x_side);
       }
     }
+    RESIDENT_PROF(4);  // further polls
     // south: {2, 5, 6} of its top row; north: {4, 7, 8} of its row 0; 5 and 8 come from the west column, 6 and 7 from the east
     const float side_s = __uint_as_float((unsigned)(first ? ss.y : ss.z)), side_n = __uint_as_float((unsigned)(first ? sn.z : sn.y));
     te[2].x = __uint_as_float((unsigned)cs.x);
@@ -1834,15 +1868,21 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
       re[k] = ne[k];
       if constexpr (ROWS == 4) ri[k] = ni[k];
     }
+    RESIDENT_PROF(5);  // collision(s)
     // the neighbours wait for exactly these rows: out they go, before anything else
     if (s + 1 < a.n_steps && alive) publish(s + 1);
     // blocked cells report 0; sum over the wave, one partial per wave into LDS (summed after the next barrier)
     const float tot = wave_sum_dpp(sum);
     if (lane == 63) wave_part[slot][wave] = tot;
+    RESIDENT_PROF(6);  // publish, wave sum
     // (a wave that gave up leaves the loop alone: the hardware barrier counts only waves that have not ended, and
     // the others find *status set in their next spin)
   }
 
+#ifdef LBM_RESIDENT_PROFILE
+  if (x == 0)
+    for (int i = 0; i < 8; i++) a.prof[b * 8 + i] = prof_acc[i];
+#endif
   __syncthreads();
   if (a.n_steps > 0 && wave == 0) {
     const float v = row16_sum_dpp((lane < n_waves) ? wave_part[(a.n_steps - 1) & 1][lane] : 0.f);
