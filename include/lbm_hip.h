@@ -54,6 +54,16 @@ extern "C" {
                             misses 1 % in dense decompositions: av_vels 4.7 % (128x256 / 2 slabs, step 2),
                             4.0 % (128x128 / 8 slabs, mid-transient), 1.2 % (256x256 / 4 slabs);
                             pressure stays within 0.01 % */
+#define LBM_HALO_FRESHEST 2 /* EXPERIMENTAL.  The reference's rule itself -- post the exchange, relax the interior rows,
+                            look ONCE whether the halo rows have arrived, relax the boundary rows either way
+                            (MPI_Testall_OptimizedVersion/d2q9-bgk.c:262-290) -- with two guarantees the reference
+                            does not give: a halo row is this step's or the step before's, never older (the stale
+                            mode's exchange backs it), and never torn (whole rows are adopted, by a look at an id
+                            that travels behind them).  Which of the two each side got in each step is logged
+                            (lbm_read_halo_log); given the log the run is reproducible on the CPU
+                            (tests/slab_model.py).  Results lie between the synchronous and the stale run and
+                            differ from run to run.  Parity unpinned, as for LBM_HALO_STALE.  RCCL and
+                            device-copy transports only */
 
 /* Run constants: field-for-field the reference's t_param (SerialCode/d2q9-bgk.c:66-75). */
 typedef struct {
@@ -81,7 +91,7 @@ typedef struct {
   int    steps_per_launch; /* timesteps one launch of the main kernel advances: 2-4 for the stream kernels
                               (three from 300 Ki cells, four from 3.5 Mi cells per slab), 3-4 for the LDS-tile
                               kernel (small single slabs), else 1 */
-  int    halo_mode;      /* LBM_HALO_SYNC or LBM_HALO_STALE (meaningful with several slabs / ranks) */
+  int    halo_mode;      /* LBM_HALO_SYNC, LBM_HALO_STALE or LBM_HALO_FRESHEST (meaningful with several slabs / ranks) */
   int    band_rows;      /* launch geometry of the multi-step stream kernel: rows one wave sweeps ... */
   int    lane_cells;     /* ... and cells per lane (4 or 2); 0 / 0 when another kernel is the main one */
   int    nontemporal;    /* 1: the step kernels store with the nontemporal hint */
@@ -251,14 +261,23 @@ void     lbm_destroy(lbm_ctx* ctx);
 int      lbm_get_info(const lbm_ctx* ctx, lbm_info* out);
 
 /*
- * Halo treatment for the following lbm_run calls (default LBM_HALO_SYNC, or LBM_HALO_STALE when the
- * environment holds LBM_HALO_MODE=stale).  Replaces the choice between the reference's
+ * Halo treatment for the following lbm_run calls (default LBM_HALO_SYNC, or LBM_HALO_STALE / LBM_HALO_FRESHEST when
+ * the environment holds LBM_HALO_MODE=stale / freshest).  Replaces the choice between the reference's
  * MPI_Waitall and MPI_Testall_OptimizedVersion programs (main loop :256-301 of the latter).
  * In stale mode every lbm_run call starts from freshly exchanged halos; from its second pass on, a
  * pass reads the halo rows its neighbours produced one pass earlier.  Every rank of a multi-process
  * run must select the same mode.  No effect on a single periodic slab.
  */
 int      lbm_set_halo_mode(lbm_ctx* ctx, int mode);
+
+/*
+ * LBM_HALO_FRESHEST's record of what each look found: out[t * n_slabs + s], timesteps t < n_steps <= steps done,
+ * slabs s of this context (n_slabs = info.n_slabs; 1 for rank contexts): bit 0 set = the south halo row of that
+ * step was the neighbour's row of the same step, bit 1 = the north one; a clear bit = the row of the step before.
+ * Steps run in the other modes read 3 (synchronous; first pass of every call) or are not recorded (stale).
+ * The reference has no counterpart: its MPI_Testall result is discarded (d2q9-bgk.c:279-280).
+ */
+int      lbm_read_halo_log(lbm_ctx* ctx, unsigned char* out, int n_steps);
 
 /* ---- the hot path ------------------------------------------------------------------------
  * lbm_run replaces n_steps trips of the driver loop (SerialCode/d2q9-bgk.c:166-170):

@@ -34,7 +34,9 @@ RCCL_ID_BYTES = 128
 MASK_HALO_ROWS = 3        # LBM_MASK_HALO_ROWS of include/lbm_hip.h
 HALO_SYNC = 0
 HALO_STALE = 1
-_HALO = {"sync": HALO_SYNC, "stale": HALO_STALE, HALO_SYNC: HALO_SYNC, HALO_STALE: HALO_STALE}
+HALO_FRESHEST = 2
+_HALO = {"sync": HALO_SYNC, "stale": HALO_STALE, "freshest": HALO_FRESHEST,
+         HALO_SYNC: HALO_SYNC, HALO_STALE: HALO_STALE, HALO_FRESHEST: HALO_FRESHEST}
 
 # every symbol include/lbm_hip.h declares (tests check the .so exports them all)
 ABI_SYMBOLS = (
@@ -42,7 +44,7 @@ ABI_SYMBOLS = (
     "lbm_partition_rows", "lbm_halo_plan", "lbm_plan_halo_depth", "lbm_create", "lbm_rccl_unique_id", "lbm_rccl_info", "lbm_create_rank", "lbm_create_rank_rows",
     "lbm_create_tiled", "lbm_create_rank_tiled", "lbm_create_rank_hosted", "lbm_create_rank_hosted_rows",
     "lbm_create_rank_hosted_tiled", "lbm_destroy",
-    "lbm_get_info", "lbm_set_halo_mode", "lbm_run", "lbm_sync", "lbm_run_timed", "lbm_read_av_vels", "lbm_read_cells",
+    "lbm_get_info", "lbm_set_halo_mode", "lbm_read_halo_log", "lbm_run", "lbm_sync", "lbm_run_timed", "lbm_read_av_vels", "lbm_read_cells",
     "lbm_read_final_state", "lbm_av_velocity", "lbm_total_density", "lbm_calc_reynolds",
 )
 
@@ -152,6 +154,7 @@ def load_library() -> ctypes.CDLL:
     lib.lbm_destroy.argtypes = [P]; lib.lbm_destroy.restype = None
     lib.lbm_get_info.argtypes = [P, ctypes.POINTER(_CInfo)]; lib.lbm_get_info.restype = I
     lib.lbm_set_halo_mode.argtypes = [P, I]; lib.lbm_set_halo_mode.restype = I
+    lib.lbm_read_halo_log.argtypes = [P, ctypes.c_void_p, I]; lib.lbm_read_halo_log.restype = I
     lib.lbm_run.argtypes = [P, I]; lib.lbm_run.restype = I
     lib.lbm_sync.argtypes = [P]; lib.lbm_sync.restype = I
     lib.lbm_run_timed.argtypes = [P, I, PF]; lib.lbm_run_timed.restype = I
@@ -362,11 +365,19 @@ class Engine:
         return _rccl_status(self.lib, self.handle)
 
     def set_halo_mode(self, mode) -> None:
-        """'sync' (halo rows of the same timestep, the MPI_Waitall pattern) or 'stale' (one pass
-        old: reproducible analogue of the reference's MPI_Testall variant)."""
+        """'sync' (halo rows of the same timestep, the MPI_Waitall pattern), 'stale' (one pass
+        old: reproducible analogue of the reference's MPI_Testall variant) or 'freshest' (the rows of this
+        step where they have arrived by the time the interior rows are done, else the rows of the step before)."""
         if mode not in _HALO:
             raise LbmError(f"unknown halo mode {mode!r}")
         _check(self.lib, self.lib.lbm_set_halo_mode(self.handle, _HALO[mode]))
+
+    def halo_log(self, n_steps: int) -> np.ndarray:
+        """uint8 [n_steps, n_slabs]: what each look of the 'freshest' mode found (bit 0 south, bit 1 north halo row
+        fresh); lbm_read_halo_log."""
+        out = np.zeros((int(n_steps), self.info()["n_slabs"]), dtype=np.uint8)
+        _check(self.lib, self.lib.lbm_read_halo_log(self.handle, out.ctypes.data, int(n_steps)))
+        return out
 
     # -- hot path ----------------------------------------------------------------------------
     def run(self, n_steps: int) -> None:

@@ -178,6 +178,13 @@ struct Slab {
   hipEvent_t ev_step = nullptr;                    // stale-halo mode: whole-slab pass finished; graph replay: join
   hipEvent_t ev_fork = nullptr;                    // graph replay: the other streams join the capture / follow the chunks
   hipEvent_t ev_x[2] = {nullptr, nullptr};         // stale-halo mode: exchange for pass m landed -> [(m + 1) & 1]
+  // freshest-available mode (LBM_HALO_FRESHEST), allocated at its first use
+  float* fresh_stage = nullptr;          // [parity][side: 0 south halo, 1 north halo][row_pitch]: this pass's rows, if they make it
+  unsigned* fresh_arrived = nullptr;     // [parity][side]: id (global step + 1) of the step whose row the staging holds
+  unsigned* fresh_id_src = nullptr;      // [parity]: the id this slab ships behind its rows (device copies)
+  int* fresh_decision = nullptr;         // bit 0 / 1: south / north staging row adopted in the current pass
+  unsigned char* fresh_log = nullptr;    // [capacity]: the decision of every step (3 where the halos were fresh anyway)
+  hipEvent_t ev_fresh[2] = {nullptr, nullptr};  // LBM_FRESH_FORCE=wait: this pass's rows and ids are out
   ncclComm_t nccl = nullptr;
   lbm::SlotCounts slot_counts;  // partials written into each buffered slot (launch geometries differ)
   int blocks_main = 0;      // interior rows (or all rows in HALO_SELF)
@@ -1175,7 +1182,7 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
   if (c->steps_done + n_steps > c->capacity)
     LBM_FAIL(LBM_FAILURE, "lbm_run: %d steps requested but the av_vels record holds %d (maxIters)",
              c->steps_done + n_steps, c->capacity);
-  if (c->halo != HALO_SELF && c->halo_mode == LBM_HALO_STALE) return run_steps_stale(c, n_steps, kernel_ms);
+  if (c->halo != HALO_SELF && c->halo_mode != LBM_HALO_SYNC) return run_steps_stale(c, n_steps, kernel_ms);
 
   const float a1 = c->p.density * c->p.accel / 9.f;
   const float a2 = c->p.density * c->p.accel / 36.f;
@@ -1234,6 +1241,109 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
   return kernel_ms ? read_step_timing(c, n_steps, kernel_ms) : LBM_SUCCESS;
 }
 
+// ---- freshest-available halo mode ------------------------------------------------------------------------------
+int ensure_fresh_buffers(lbm_ctx* c) {
+  for (int s = 0; s < c->n_slabs; s++) {
+    Slab& sl = c->slab[s];
+    if (sl.fresh_stage) continue;
+    HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+    HIP_TRY(LBM_FAILURE, hipMalloc(&sl.fresh_stage, 4 * (size_t)c->row_pitch * sizeof(float)));
+    HIP_TRY(LBM_FAILURE, hipMalloc(&sl.fresh_arrived, 4 * sizeof(unsigned)));
+    HIP_TRY(LBM_FAILURE, hipMalloc(&sl.fresh_id_src, 2 * sizeof(unsigned)));
+    HIP_TRY(LBM_FAILURE, hipMalloc(&sl.fresh_decision, sizeof(int)));
+    HIP_TRY(LBM_FAILURE, hipMalloc(&sl.fresh_log, (size_t)c->capacity));
+    HIP_TRY(LBM_FAILURE, hipMemset(sl.fresh_arrived, 0, 4 * sizeof(unsigned)));
+    HIP_TRY(LBM_FAILURE, hipMemset(sl.fresh_decision, 0, sizeof(int)));
+    HIP_TRY(LBM_FAILURE, hipMemset(sl.fresh_log, 3, (size_t)c->capacity));  // synchronous and first passes: both sides fresh
+    for (int i = 0; i < 2; i++) HIP_TRY(LBM_FAILURE, hipEventCreateWithFlags(&sl.ev_fresh[i], hipEventDisableTiming));
+  }
+  return LBM_SUCCESS;
+}
+
+// F(m): the boundary rows of the lattice `src` (timestep id - 1 of the run, just produced) travel towards the staging
+// rows [par] of the ring neighbours, each followed in stream order by `id`.  Same preconditions as the stale exchange
+// (exchange_halos, slot >= 0): behind ev_step of this slab and, where this slab writes into its neighbours' memory
+// itself, of the neighbours -- their previous pass, the last reader of staging [par] (two passes ago), is over.
+// Nobody ever waits for it (LBM_FRESH_FORCE=wait excepted: tests).
+int fresh_exchange(lbm_ctx* c, int src, int par, unsigned id) {
+  const long n = c->row_pitch;
+  // tests: hold about half of the (step, slab) exchanges back by so many microseconds, so that looks miss them
+  const int delay_us = env_int("LBM_FRESH_TEST_DELAY_US", 0);
+  auto delayed = [&](int s) { return delay_us > 0 && ((((id * 2654435761u) >> 11) ^ (unsigned)s) & 1u) != 0; };
+  if (c->halo == HALO_RCCL) {
+    for (int s = 0; s < c->n_slabs; s++) {
+      Slab& sl = c->slab[s];
+      HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+      HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sl.ev_step, 0));
+      if (delayed(s)) hipLaunchKernelGGL(lbm::fresh_test_delay, dim3(1), dim3(1), 0, sl.comm, (long long)delay_us * 100);
+    }
+    RCCL_OR_FAIL(LBM_FAILURE);
+    const RcclApi& nc = *rc_api_;
+    if (!c->team) NCCL_TRY(LBM_FAILURE, nc.GroupStart());
+    int rc = for_slabs(c, [&](int s) -> int {
+      Slab& sl = c->slab[s];
+      int me, parts;
+      if (c->ranked) { me = c->rank; parts = c->world; } else { me = s; parts = c->n_slabs; }
+      lbm_halo_op ops[4];
+      if (lbm_halo_plan(sl.rows, parts, me, 1, ops) != LBM_SUCCESS) return LBM_FAILURE;
+      if (c->team) {
+        HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+        NCCL_TRY(LBM_FAILURE, nc.GroupStart());
+      }
+      ncclResult_t res = ncclSuccess;
+      for (int i = 0; i < 4 && res == ncclSuccess; i++) {
+        // a receive of halo row -1 (rows) lands in the south (north) staging row instead
+        float* ptr = ops[i].is_send ? sl.lat[src] + (long)ops[i].row_first * c->row_pitch
+                                    : sl.fresh_stage + ((long)par * 2 + (ops[i].row_first < 0 ? 0 : 1)) * n;
+        res = ops[i].is_send ? nc.Send(ptr, (size_t)n, ncclFloat, ops[i].peer, sl.nccl, sl.comm)
+                             : nc.Recv(ptr, (size_t)n, ncclFloat, ops[i].peer, sl.nccl, sl.comm);
+      }
+      if (c->team) {
+        const ncclResult_t end = nc.GroupEnd();
+        if (res == ncclSuccess) res = end;
+      }
+      if (res != ncclSuccess) LBM_FAIL(LBM_FAILURE, "RCCL error in the halo exchange: %s", nc.GetErrorString(res));
+      return LBM_SUCCESS;
+    });
+    if (!c->team) {
+      const ncclResult_t end = nc.GroupEnd();
+      if (rc == LBM_SUCCESS && end != ncclSuccess) { raise_error(__LINE__, "RCCL error: %s (ncclGroupEnd)", nc.GetErrorString(end)); rc = LBM_FAILURE; }
+    }
+    if (rc != LBM_SUCCESS) return rc;
+    for (int s = 0; s < c->n_slabs; s++) {
+      Slab& sl = c->slab[s];
+      HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+      hipLaunchKernelGGL(lbm::fresh_mark, dim3(1), dim3(1), 0, sl.comm, sl.fresh_arrived + par * 2, sl.fresh_arrived + par * 2 + 1, id);
+      HIP_TRY(LBM_FAILURE, hipGetLastError());
+      HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_fresh[par], sl.comm));
+    }
+    return LBM_SUCCESS;
+  }
+  if (c->halo == HALO_MEMCPY) {
+    return for_slabs(c, [&](int s) -> int {
+      Slab& sl = c->slab[s];
+      Slab& sn = c->slab[(s + 1) % c->n_slabs];
+      Slab& ss = c->slab[(s - 1 + c->n_slabs) % c->n_slabs];
+      HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+      HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sl.ev_step, 0));
+      HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, sn.ev_step, 0));
+      HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.comm, ss.ev_step, 0));
+      if (delayed(s)) hipLaunchKernelGGL(lbm::fresh_test_delay, dim3(1), dim3(1), 0, sl.comm, (long long)delay_us * 100);
+      hipLaunchKernelGGL(lbm::fresh_mark, dim3(1), dim3(1), 0, sl.comm, sl.fresh_id_src + par, (unsigned*)nullptr, id);
+      HIP_TRY(LBM_FAILURE, hipGetLastError());
+      // my top row is my north neighbour's south halo row, my row 0 my south neighbour's north halo row
+      HIP_TRY(LBM_FAILURE, hipMemcpyAsync(sn.fresh_stage + ((long)par * 2 + 0) * n, sl.lat[src] + (long)(sl.rows - 1) * c->row_pitch,
+                                          (size_t)n * sizeof(float), hipMemcpyDefault, sl.comm));
+      HIP_TRY(LBM_FAILURE, hipMemcpyAsync(sn.fresh_arrived + par * 2 + 0, sl.fresh_id_src + par, sizeof(unsigned), hipMemcpyDefault, sl.comm));
+      HIP_TRY(LBM_FAILURE, hipMemcpyAsync(ss.fresh_stage + ((long)par * 2 + 1) * n, sl.lat[src], (size_t)n * sizeof(float), hipMemcpyDefault, sl.comm));
+      HIP_TRY(LBM_FAILURE, hipMemcpyAsync(ss.fresh_arrived + par * 2 + 1, sl.fresh_id_src + par, sizeof(unsigned), hipMemcpyDefault, sl.comm));
+      HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_fresh[par], sl.comm));
+      return LBM_SUCCESS;
+    });
+  }
+  LBM_FAIL(LBM_FAILURE, "the freshest-available halo mode is not available with the hosted exchange");
+}
+
 // Stale-halo ("asynchronous") timestep loop: the GPU analogue of the reference's research variant,
 // MPI_Testall_OptimizedVersion/d2q9-bgk.c:256-301, which replaces MPI_Waitall by MPI_Testall and relaxes
 // the boundary rows with whatever halo contents are there.  Here the staleness is pinned to exactly
@@ -1256,10 +1366,24 @@ int run_steps(lbm_ctx* c, int n_steps, float* kernel_ms) {
 // redundantly relaxed halo-adjacent rows would be computed from stale data on one side of the seam and
 // from fresh data on the other, which no longer conserves mass: measured, that variant drifts past the
 // 1 % rule with 2 slabs and diverges to NaN after 2172 steps with 8 (profiles/r01_tuning.md).
+//
+// LBM_HALO_FRESHEST on top of that -- the reference's rule itself, "look once, never wait" (MPI_Testall_Optimized
+// Version/d2q9-bgk.c:262-290: post the exchange, relax the interior rows, MPI_Testall, relax the boundary rows with
+// whatever is there): the rows of lattice k ALSO travel (F(k), first on the comm stream) towards a staging row per
+// side, followed by the step's id; S(k) is cut into interior rows, one look at the ids (fresh_decide: which sides have
+// arrived, noted in the log), whole staging rows moved over the one-pass-old halo rows where they have (fresh_adopt),
+// boundary rows.  Every halo row is the row of this pass or of the pass before -- never older, never torn -- and
+// given the log of decisions the run is reproducible (tests/slab_model.py: run_slabs_freshest).
 int run_steps_stale(lbm_ctx* c, int n_steps, float* kernel_ms) {
   const float a1 = c->p.density * c->p.accel / 9.f;
   const float a2 = c->p.density * c->p.accel / 36.f;
   const int depth = 1;  // one timestep per pass (see above): only the adjacent row is read
+  const bool freshest = (c->halo_mode == LBM_HALO_FRESHEST);
+  // tests: "wait" makes every look find its rows (= the synchronous run), "never" sends none (= the stale mode)
+  const char* force_env = freshest ? getenv("LBM_FRESH_FORCE") : nullptr;
+  const bool force_wait = force_env && !strcmp(force_env, "wait"), force_never = force_env && !strcmp(force_env, "never");
+  if (freshest && c->halo == HALO_HOST) LBM_FAIL(LBM_FAILURE, "the freshest-available halo mode is not available with the hosted exchange");
+  if (freshest && ensure_fresh_buffers(c) != LBM_SUCCESS) return LBM_FAILURE;
   HotGuard hot_guard(c->team);
 
   // accelerate_flow() of the first step, then fresh halos for pass 0 (same lattice) and, from the same
@@ -1297,16 +1421,46 @@ int run_steps_stale(lbm_ctx* c, int n_steps, float* kernel_ms) {
             HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, c->slab[north].ev_x[slot], 0));
             HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, c->slab[south].ev_x[slot], 0));
           }
-          if (launch_step(c, s, sl.compute, 0, 1, sl.rows, 0, !last) != LBM_SUCCESS) return LBM_FAILURE;
+          if (!freshest) {
+            if (launch_step(c, s, sl.compute, 0, 1, sl.rows, 0, !last) != LBM_SUCCESS) return LBM_FAILURE;
+          } else {
+            const int par = m & 1;
+            const unsigned id = (unsigned)(c->steps_done + m) + 1u;
+            if (launch_step(c, s, sl.compute, 1, 1, sl.rows - 2, 0, !last) != LBM_SUCCESS) return LBM_FAILURE;
+            if (m > 0 && force_wait) {
+              if (c->halo == HALO_MEMCPY) {
+                const int north = (s + 1) % c->n_slabs, south = (s - 1 + c->n_slabs) % c->n_slabs;
+                HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, c->slab[north].ev_fresh[par], 0));
+                HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, c->slab[south].ev_fresh[par], 0));
+              } else {
+                HIP_TRY(LBM_FAILURE, hipStreamWaitEvent(sl.compute, sl.ev_fresh[par], 0));
+              }
+            }
+            hipLaunchKernelGGL(lbm::fresh_decide, dim3(1), dim3(1), 0, sl.compute, (const unsigned*)(sl.fresh_arrived + par * 2), id,
+                               m == 0 ? 1 : 0, sl.fresh_decision, sl.fresh_log + c->steps_done + m);
+            HIP_TRY(LBM_FAILURE, hipGetLastError());
+            if (m > 0) {
+              const long n = c->row_pitch;
+              float* lat = sl.lat[c->cur];
+              hipLaunchKernelGGL(lbm::fresh_adopt, dim3(ceil_div(n, 256)), dim3(256), 0, sl.compute, (const int*)sl.fresh_decision,
+                                 (const unsigned*)(sl.fresh_stage + ((long)par * 2 + 0) * n), (const unsigned*)(sl.fresh_stage + ((long)par * 2 + 1) * n),
+                                 (unsigned*)(lat - n), (unsigned*)(lat + (long)sl.rows * c->row_pitch), n);
+              HIP_TRY(LBM_FAILURE, hipGetLastError());
+            }
+            if (launch_step(c, s, sl.compute, 0, sl.rows - 1, 2, sl.blocks_main, !last) != LBM_SUCCESS) return LBM_FAILURE;
+          }
           HIP_TRY(LBM_FAILURE, hipEventRecord(sl.ev_step, sl.compute));
           return LBM_SUCCESS;
         }) != LBM_SUCCESS)
       return LBM_FAILURE;
     for (int s = 0; s < c->n_slabs; s++)
-      c->slab[s].slot_counts.n[c->slot_fill] = blocks_for_rows(c, c->slab[s].rows);
+      c->slab[s].slot_counts.n[c->slot_fill] = freshest ? c->slab[s].blocks_main + c->slab[s].blocks_boundary : blocks_for_rows(c, c->slab[s].rows);
     c->cur ^= 1;
     c->slot_fill += 1;
-    // X'(m+1): the rows S(m) just produced, for S(m+2)
+    // F(m+1): the rows S(m) just produced, for S(m+1) itself if they get there before its look
+    if (!last && freshest && !force_never && fresh_exchange(c, c->cur, (m + 1) & 1, (unsigned)(c->steps_done + m + 1) + 1u) != LBM_SUCCESS)
+      return LBM_FAILURE;
+    // X'(m+1): the same rows, for S(m+2)
     if (!last && exchange_halos(c, depth, c->cur, c->cur ^ 1, slot) != LBM_SUCCESS) return LBM_FAILURE;
     if (c->slot_fill >= kPartSlots - 1 || last) {
       if (flush_partials(c, flushed_upto) != LBM_SUCCESS) return LBM_FAILURE;
@@ -1338,6 +1492,12 @@ void free_slab(Slab& sl) {
   if (sl.scratch) (void)hipFree(sl.scratch);
   if (sl.reduce_buf) (void)hipFree(sl.reduce_buf);
   if (sl.flushed_dev) (void)hipFree(sl.flushed_dev);
+  if (sl.fresh_stage) (void)hipFree(sl.fresh_stage);
+  if (sl.fresh_arrived) (void)hipFree(sl.fresh_arrived);
+  if (sl.fresh_id_src) (void)hipFree(sl.fresh_id_src);
+  if (sl.fresh_decision) (void)hipFree(sl.fresh_decision);
+  if (sl.fresh_log) (void)hipFree(sl.fresh_log);
+  for (int i = 0; i < 2; i++) if (sl.ev_fresh[i]) (void)hipEventDestroy(sl.ev_fresh[i]);
   if (sl.res_gran) (void)hipFree(sl.res_gran);
   if (sl.res_part) (void)hipFree(sl.res_part);
   if (sl.res_status) (void)hipFree(sl.res_status);
@@ -1612,6 +1772,14 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
         warned = true;
         fprintf(stderr, "lbm_hip: LBM_HALO_MODE=stale is EXPERIMENTAL: halo rows one pass old; results differ from the "
                         "synchronous run (measured up to 4.7 %% on av_vels mid-transient, outside check.py's 1 %% rule)\n");
+      }
+    } else if (hm && !strcmp(hm, "freshest") && !c->hosted) {
+      c->halo_mode = LBM_HALO_FRESHEST;
+      static bool warned = false;
+      if (!warned && c->halo != HALO_SELF && rank == 0) {
+        warned = true;
+        fprintf(stderr, "lbm_hip: LBM_HALO_MODE=freshest is EXPERIMENTAL: every halo row is this step's or the step before's, "
+                        "whichever has arrived; results differ from the synchronous run and from run to run\n");
       }
     }
   }
@@ -2116,7 +2284,7 @@ int lbm_get_info(const lbm_ctx* c, lbm_info* out) {
   out->math_mode = c->math_mode;
   out->world_rank = c->rank;
   out->world_size = c->world;
-  const bool stale = (c->halo != HALO_SELF && c->halo_mode == LBM_HALO_STALE);
+  const bool stale = (c->halo != HALO_SELF && c->halo_mode != LBM_HALO_SYNC);
   out->steps_per_launch = (c->tile_steps && c->halo == HALO_SELF) ? c->tile_steps : ((c->fuse2 && !stale) ? c->pass_steps : 1);
   out->halo_mode = c->halo_mode;
   const bool stream_kernel = c->fuse2 && !stale && !(c->tile_steps && c->halo == HALO_SELF);
@@ -2135,7 +2303,8 @@ int lbm_get_info(const lbm_ctx* c, lbm_info* out) {
 
 int lbm_set_halo_mode(lbm_ctx* c, int mode) {
   if (!c) LBM_FAIL(LBM_FAILURE, "lbm_set_halo_mode: null context");
-  if (mode != LBM_HALO_SYNC && mode != LBM_HALO_STALE) LBM_FAIL(LBM_FAILURE, "lbm_set_halo_mode: unknown mode %d", mode);
+  if (mode != LBM_HALO_SYNC && mode != LBM_HALO_STALE && mode != LBM_HALO_FRESHEST) LBM_FAIL(LBM_FAILURE, "lbm_set_halo_mode: unknown mode %d", mode);
+  if (mode == LBM_HALO_FRESHEST && c->halo == HALO_HOST) LBM_FAIL(LBM_FAILURE, "lbm_set_halo_mode: the freshest-available mode is not available with the hosted exchange");
   c->halo_mode = mode;
   return LBM_SUCCESS;
 }
@@ -2163,6 +2332,25 @@ int lbm_sync(lbm_ctx* c) {
                "were not all running at once -- is another process using the device?  The lattice of this context is no "
                "longer valid; LBM_RESIDENT=0 selects the launch-per-pass kernels, LBM_RESIDENT_TIMEOUT_MS moves the bound",
                (double)c->resident_timeout / 1e5, status, c->resident_bands);
+  }
+  return LBM_SUCCESS;
+}
+
+int lbm_read_halo_log(lbm_ctx* c, unsigned char* out, int n) {
+  if (!c || !out) LBM_FAIL(LBM_FAILURE, "lbm_read_halo_log: NULL argument");
+  if (n < 0 || n > c->steps_done) LBM_FAIL(LBM_FAILURE, "lbm_read_halo_log: %d steps requested, %d recorded", n, c->steps_done);
+  if (n == 0) return LBM_SUCCESS;
+  if (lbm_sync(c) != LBM_SUCCESS) return LBM_FAILURE;
+  std::vector<unsigned char> part((size_t)n);
+  for (int s = 0; s < c->n_slabs; s++) {
+    Slab& sl = c->slab[s];
+    if (sl.fresh_log) {
+      HIP_TRY(LBM_FAILURE, hipSetDevice(sl.device));
+      HIP_TRY(LBM_FAILURE, hipMemcpy(part.data(), sl.fresh_log, (size_t)n, hipMemcpyDeviceToHost));
+    } else {
+      part.assign((size_t)n, 3);  // the mode was never used: every halo row was the row of its step
+    }
+    for (int t = 0; t < n; t++) out[(size_t)t * c->n_slabs + s] = part[(size_t)t];
   }
   return LBM_SUCCESS;
 }

@@ -1970,6 +1970,46 @@ __global__ void accelerate_row(float* lat, const unsigned char* mask, long ps, l
   lat[6 * ps + c] = f[6];  lat[7 * ps + c] = f[7];  lat[8 * ps + c] = f[8];
 }
 
+// ---------------------------------------------------------------------------------------------
+// "freshest available" halo mode (LBM_HALO_FRESHEST): the reference's MPI_Testall idea, MPI_Testall_OptimizedVersion/
+// d2q9-bgk.c:279-290 -- look once whether this step's halo rows have arrived, never wait for them.  The rows travel
+// into a staging row per side, followed in stream order by the id of the step they belong to (fresh_mark / a 4-byte
+// copy); after the interior rows, fresh_decide looks at the ids ONCE, notes which sides made it (the engine's log of
+// decisions) and fresh_adopt moves those staging rows into the halo rows, whole rows only.  The sides that did not make
+// it keep the rows of the step before, which the one-pass-late exchange of the stale mode has put there.
+// ---------------------------------------------------------------------------------------------
+__global__ void fresh_mark(unsigned* a, unsigned* b, unsigned id) {
+  if (a) __hip_atomic_store(a, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (b) __hip_atomic_store(b, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// tests (LBM_FRESH_TEST_DELAY_US): holds a comm stream back so that looks find nothing; bounded by the clock
+__global__ void fresh_test_delay(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+// arrived[0] / arrived[1]: id of the step whose south / north halo row the staging holds; mode 0: look (the product),
+// 1: this pass's halo rows are fresh anyway (first pass of a call): note 3, adopt nothing
+__global__ void fresh_decide(const unsigned* arrived, unsigned id, int mode, int* decision, unsigned char* log_entry) {
+  unsigned d = 0;
+  if (mode == 0) {
+    d = (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == id ? 1u : 0u) |
+        (__hip_atomic_load(arrived + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == id ? 2u : 0u);
+    *decision = (int)d;
+  } else {
+    *decision = 0;
+    d = 3;
+  }
+  *log_entry = (unsigned char)d;
+}
+// staging rows (written by a peer: read past the caches) -> halo rows, per side as decided
+__global__ void fresh_adopt(const int* decision, const unsigned* stage_s, const unsigned* stage_n, unsigned* halo_s, unsigned* halo_n, long n) {
+  const int d = *decision;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (d & 1) halo_s[i] = __hip_atomic_load(stage_s + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (d & 2) halo_n[i] = __hip_atomic_load(stage_n + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // sum the per-workgroup partials of up to gridDim.x steps: block s adds partials[s][0..n[s])
 // in a fixed order (double accumulation) -> tot_u[step_base + s].  Deterministic, no atomics.
 constexpr int kPartSlotsMax = 64;

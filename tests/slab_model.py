@@ -100,3 +100,50 @@ def run_slabs(oracle, lbm, p, ob, calls, n_slabs, lag=0, two_step=True, cells=No
     for sl in slabs:
         out[:, sl.first:sl.first + sl.rows] = sl.buf[cur][:, H:H + sl.rows]
     return np.ascontiguousarray(out.transpose(1, 2, 0)), tot_u
+
+
+def run_slabs_freshest(oracle, lbm, p, ob, calls, n_slabs, schedule=None, p_fresh=None, seed=0, cells=None):
+    """LBM_HALO_FRESHEST, i.e. the reference's own rule (/root/reference/MPI_Testall_OptimizedVersion/d2q9-bgk.c:256-301:
+    look once, then relax the boundary rows with whatever the halo rows hold) with the engine's two guarantees: in
+    every pass each side of each slab finds either its neighbour's row of THIS pass (bit set in schedule[step, slab]:
+    bit 0 south, bit 1 north -- the engine's lbm_read_halo_log) or the row of the pass before, which the one-pass-late
+    exchange of the stale mode has put there; whole rows.  Without a schedule the bits are drawn with probability
+    p_fresh (1 = the synchronous run, 0 = the stale mode).  The first pass of every call starts from fresh halos.
+    Returns (lattice (ny, nx, 9), tot_u float64[steps], total density of the fluid cells after every step, the schedule)."""
+    rng = np.random.default_rng(seed)
+    total = sum(calls)
+    if schedule is None:
+        schedule = (rng.random((total, n_slabs)) < p_fresh).astype(np.uint8) | ((rng.random((total, n_slabs)) < p_fresh).astype(np.uint8) << 1)
+    full = np.ascontiguousarray((oracle.init_cells(p) if cells is None else cells).transpose(2, 0, 1))
+    slabs = []
+    for s in range(n_slabs):
+        first, rows = lbm.partition_rows(p.ny, n_slabs, s)
+        slabs.append(_Slab(oracle, p, ob, full, first, rows))
+    fluid = [(ob[sl.first:sl.first + sl.rows] == 0) for sl in slabs]
+    tot_u = np.zeros(total, dtype=np.float64)
+    mass = np.zeros(total, dtype=np.float64)
+    cur, done = 0, 0
+    for n_steps in calls:
+        for m in range(n_steps):
+            for sl in slabs:
+                if sl.lid is not None and 0 <= sl.lid < sl.rows:
+                    sl.accelerate(sl.buf[cur], sl.lid)
+            if m == 0:
+                _deliver(slabs, cur, cur, 1)
+            else:
+                for s, sl in enumerate(slabs):      # the rows of this pass, where they made it in time
+                    north, south = slabs[(s + 1) % n_slabs], slabs[(s - 1 + n_slabs) % n_slabs]
+                    if schedule[done + m, s] & 1:
+                        sl.buf[cur][:, H - 1:H] = south.buf[cur][:, H + south.rows - 1:H + south.rows]
+                    if schedule[done + m, s] & 2:
+                        sl.buf[cur][:, H + sl.rows:H + sl.rows + 1] = north.buf[cur][:, H:H + 1]
+            _deliver(slabs, cur, cur ^ 1, 1)        # one pass late for the next pass, guaranteed
+            for sl in slabs:
+                tot_u[done + m] += sl.relax(sl.buf[cur], sl.buf[cur ^ 1], 0, sl.rows - 1)
+            cur ^= 1
+            mass[done + m] = sum(float(sl.buf[cur][:, H:H + sl.rows].sum(axis=0, dtype=np.float64)[f].sum()) for sl, f in zip(slabs, fluid))
+        done += n_steps
+    out = np.empty((9, p.ny, p.nx), dtype=np.float32)
+    for sl in slabs:
+        out[:, sl.first:sl.first + sl.rows] = sl.buf[cur][:, H:H + sl.rows]
+    return np.ascontiguousarray(out.transpose(1, 2, 0)), tot_u, mass, schedule

@@ -101,23 +101,28 @@ def test_cli_multi_slab_full_run_matches_serialcode_bytes(lbm, tmp_path, name, g
     np.testing.assert_allclose(av, ref["av_vels"].astype(np.float64), rtol=5e-4)
 
 
+@pytest.mark.parametrize("mode", ["stale", "freshest"])
 @pytest.mark.parametrize("name,gpus", [("128x256", "2"), ("256x256", "4")])
-def test_cli_stale_halo_mode_deviation_is_bounded(lbm, golden, tmp_path, name, gpus):
-    """LBM_HALO_MODE=stale through the command line (the reference ships this as a separate program,
+def test_cli_stale_halo_mode_deviation_is_bounded(lbm, golden, tmp_path, name, gpus, mode):
+    """LBM_HALO_MODE=stale / freshest through the command line (the reference ships this as a separate program,
     MPI_Testall_OptimizedVersion/d2q9-bgk.c).  The engine's stale mode is the WORST case of that
     program -- every halo exactly one step late, every step -- so it does not always meet check.py's 1 %
     rule on av_vels, which takes the maximum over all steps including the first few, where only a handful
     of rows move at all: measured 4.7 % at step 2 on 128x256 (2 slabs: the seam lies two rows from the
     accelerated row) and 1.2 % at step 9145 on 256x256 (4 slabs).  Asserted here: av_vels within 5 %
-    at every step and within 1 % at the end, the pressure field within the 1 % rule."""
+    at every step and within 1 % at the end, the pressure field within the 1 % rule.  The freshest-available mode
+    lies between that and the synchronous run (on this box, where the slabs share a device, its looks nearly always
+    find the fresh rows)."""
     pf = os.path.join(GOLDEN, "inputs", f"input_{name}.params")
     of = os.path.join(GOLDEN, "inputs", f"obstacles_{name}.dat")
-    env = dict(os.environ, LBM_GPUS=gpus, LBM_HALO="memcpy", LBM_HALO_MODE="stale")
+    env = dict(os.environ, LBM_GPUS=gpus, LBM_HALO="memcpy", LBM_HALO_MODE=mode)
     out = subprocess.run([lbm.CLI_PATH, pf, of], cwd=tmp_path, capture_output=True, text=True, env=env)
     assert out.returncode == 0, out.stderr
     gold = np.load(os.path.join(golden, "check_goldens.npz"))
     ref = np.load(os.path.join(GOLDEN, f"serialcode_{name}.npz"))
-    assert md5(tmp_path / "final_state.dat") != str(ref["md5_final_state"])      # the mode really was on
+    assert "EXPERIMENTAL" in out.stderr
+    if mode == "stale":
+        assert md5(tmp_path / "final_state.dat") != str(ref["md5_final_state"])  # the mode really was on
     av = np.loadtxt(tmp_path / "av_vels.dat", usecols=[1])
     want = gold[f"av_vels_{name}"]
     assert lbm.check_passes(want, av, 5.0), lbm.check_rule(want, av)

@@ -26,6 +26,8 @@ hardware by tests/test_gpu_parity.py (several slabs on one device + RCCL self-ex
 import os
 import socket
 import sys
+import threading
+import time
 
 import numpy as np
 import pytest
@@ -108,6 +110,7 @@ def rank_main(rank, world, port, name, steps, out_dir, lag=0, seed=None, env=Non
                 arr[:, lo:lo + n] = t.numpy()
 
         t, m, stale = 0, 0, None
+        looks = np.full(steps, 3, dtype=np.uint8)   # lag == 2: what each look found (bit 0 south, bit 1 north halo row)
         S = bufs[0]
         while t < steps:
             left = steps - t
@@ -118,6 +121,8 @@ def rank_main(rank, world, port, name, steps, out_dir, lag=0, seed=None, env=Non
             for r in lid_rows:
                 if 0 <= r < rows:
                     accelerate(S, r)
+            if lag == 2 and ((m * 2654435761 >> 7) ^ rank) & 1:
+                time.sleep(0.004)            # this rank's rows leave late in about half of the passes: looks will miss them
             reqs, landing = exchange(S, depth)
             if lag and m > 0:
                 # stale-halo mode (run_steps_stale): this pass reads what the neighbours sent one pass
@@ -127,6 +132,40 @@ def rank_main(rank, world, port, name, steps, out_dir, lag=0, seed=None, env=Non
             T = others[0]
             # step t on the rows whose inputs are all owned (overlaps the exchange) ...
             s_in = relax(S, T, k, rows - 1 - k)
+            if lag == 2:
+                # freshest-available mode: MPI_Testall's question, asked ONCE per receive, never waited for
+                # (/root/reference/MPI_Testall_OptimizedVersion/d2q9-bgk.c:279-290); a row that has arrived replaces
+                # the row of the pass before, whole.  (gloo's Work.is_completed() stays False until somebody waits, so
+                # a thread per receive waits and raises a flag -- the look reads the flags.)
+                arrived = [False, False]
+
+                def wait_recv(i, req):
+                    req.wait()
+                    arrived[i] = True
+                waiters = [threading.Thread(target=wait_recv, args=(i, req)) for i, req in enumerate(reqs[2:])]
+                for w in waiters:
+                    w.start()
+                if m > 0:
+                    looks[t] = 0
+                    for side, (lo, n, tt) in enumerate(landing):
+                        if arrived[side]:
+                            S[:, lo:lo + n] = tt.numpy()
+                            looks[t] |= 1 << side
+                else:
+                    for w in waiters:
+                        w.join()
+                    land(S, landing)                            # every run starts from fresh halos
+                s_b = relax(S, T, 0, 0) + relax(S, T, rows - 1, rows - 1)
+                for w in waiters:
+                    w.join()                                    # ... before the NEXT pass, as its guaranteed rows
+                for r in reqs[:2]:
+                    r.wait()
+                stale = [(lo, n, tt.clone()) for lo, n, tt in landing]
+                tot_u[t] = float(s_in) + float(s_b)
+                S = T
+                t += 1
+                m += 1
+                continue
             for r in reqs:
                 r.wait()
             if lag:
@@ -156,6 +195,12 @@ def rank_main(rank, world, port, name, steps, out_dir, lag=0, seed=None, env=Non
             t += k
             m += 1
 
+        if lag == 2:
+            mine_looks = torch.from_numpy(looks)
+            gathered = [torch.empty_like(mine_looks) for _ in range(world)]
+            dist.all_gather(gathered, mine_looks)
+            if rank == 0:
+                np.save(os.path.join(out_dir, "looks.npy"), np.stack([g.numpy() for g in gathered], axis=1))
         tot = torch.from_numpy(tot_u)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         av = (tot.numpy().astype(np.float32) / np.float32((ob == 0).sum())).astype(np.float32)
@@ -221,3 +266,28 @@ def test_stale_halo_ring_equals_slab_model(tmp_path, oracle, datasets, lbm, worl
     ref = cells.copy()
     oracle.run(p, ref, ob, steps)
     assert np.array_equal(sync.view(np.uint32), ref.view(np.uint32))      # the model itself is pinned
+
+
+@pytest.mark.parametrize("world,name,steps", [(2, "128x128", 40), (3, "128x256", 30)])
+def test_freshest_halo_ring_equals_slab_model_under_its_own_schedule(tmp_path, oracle, datasets, lbm, world, name, steps):
+    """Freshest-available mode (lbm_set_halo_mode(LBM_HALO_FRESHEST)) over real, really asynchronous messages: every
+    rank posts its exchange, relaxes its interior rows, asks each receive ONCE whether it has completed
+    (Work.is_completed(): MPI_Testall's question) and relaxes its boundary rows either way -- with this step's row
+    where it has, with the row of the step before where it has not.  Ranks send late in about half of the passes, so
+    both happen.  Whatever the looks found, the run must be the model's (tests/slab_model.py: run_slabs_freshest)
+    under the schedule the ranks logged, bit for bit -- the same statement tests/test_gpu_freshest_halo.py makes of
+    the engine and its lbm_read_halo_log."""
+    import slab_model
+    torch.set_num_threads(1)
+    mp.spawn(rank_main, args=(world, free_port(), name, steps, str(tmp_path), 2, 77), nprocs=world, join=True)
+    p, ob = datasets(name)
+    cells = random_cells(p, 77)
+    looks = np.load(tmp_path / "looks.npy")
+    assert looks.shape == (steps, world) and (looks[0] == 3).all()
+    assert (looks[1:] != 3).any(), "no look missed its rows: the delays did not bite"
+    want, want_tot, _, _ = slab_model.run_slabs_freshest(oracle, lbm, p, ob, [steps], world, schedule=looks, cells=cells)
+    got = np.ascontiguousarray(np.load(tmp_path / "lattice.npy").transpose(1, 2, 0))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    want_av = (want_tot / np.float64((ob == 0).sum())).astype(np.float32)
+    np.testing.assert_allclose(np.load(tmp_path / "av.npy"), want_av, rtol=2e-4)
+    print(f"looks that found this step's row: {np.mean([(looks[1:] & 1).mean(), ((looks[1:] >> 1) & 1).mean()]):.2f}")
