@@ -1100,6 +1100,11 @@ int replay_chunks(lbm_ctx* c, int n_steps, int first_step, int* done) {
 
 int run_steps_stale(lbm_ctx* c, int n_steps, float* kernel_ms);
 
+// seam granules: [2 directions][bands][2 slots][nx] + one XCC-id granule per band
+size_t resident_gran_bytes(const lbm_ctx* c) {
+  return (2UL * c->resident_bands * 2 * c->p.nx + c->resident_bands) * sizeof(uint4);
+}
+
 const void* resident_kernel(int nx, int rows, int joint) {
   if (rows == 2) return (nx > 512) ? reinterpret_cast<const void*>(lbm::resident_band<1024, false, 2>)
                                    : reinterpret_cast<const void*>(lbm::resident_band<512, false, 2>);
@@ -1131,7 +1136,7 @@ int run_resident(lbm_ctx* c, int n_steps) {
     a.a1 = c->p.density * c->p.accel / 9.f;
     a.a2 = c->p.density * c->p.accel / 36.f;
     a.gran = sl.res_gran;
-    a.gran_bytes = (unsigned)((2UL * c->resident_bands * 2 * c->p.nx + c->resident_bands) * sizeof(uint4));
+    a.gran_bytes = (unsigned)resident_gran_bytes(c);
     a.xcd_affinity = env_int("LBM_RESIDENT_XCD", 1) ? 1 : 0;
     a.poll_sleep = env_int("LBM_RESIDENT_SLEEP", c->p.nx > 512 ? 4 : 1);
     a.epoch0 = (unsigned)(c->steps_done + t);
@@ -1139,14 +1144,13 @@ int run_resident(lbm_ctx* c, int n_steps) {
     a.status = sl.res_status;
     a.timeout_ticks = c->resident_timeout;
     a.absent_band = env_int("LBM_RESIDENT_ABSENT_BAND", -1);  // tests of the give-up path
-    a.one_xcd = env_int("LBM_RESIDENT_ONE_XCD", 0) ? 1 : 0;
 #ifdef LBM_RESIDENT_PROFILE
     static long long* prof_dev = nullptr;
     if (!prof_dev) HIP_TRY(LBM_FAILURE, hipMalloc(&prof_dev, 1024 * 8 * sizeof(long long)));
     a.prof = prof_dev;
 #endif
     void* args[] = {&a};
-    HIP_TRY(LBM_FAILURE, hipLaunchKernel(resident_kernel(c->p.nx, c->resident_rows, c->resident_joint), dim3(c->resident_bands * (a.one_xcd ? 8 : 1)),
+    HIP_TRY(LBM_FAILURE, hipLaunchKernel(resident_kernel(c->p.nx, c->resident_rows, c->resident_joint), dim3(c->resident_bands),
                                          dim3(c->p.nx), args, 0, sl.compute));
     hipLaunchKernelGGL(lbm::reduce_band_partials, dim3(n), dim3(64), 0, sl.compute, (const float*)sl.res_part,
                        c->resident_bands, sl.tot_u, c->steps_done + t);
@@ -1562,7 +1566,7 @@ int build_slab(lbm_ctx* c, int s, const ObstacleSource& obst, const float* cells
   HIP_TRY(LBM_FAILURE, hipMalloc(&sl.flushed_dev, sizeof(int)));
   if (c->resident) {
     // granules start at tag 0 = "nothing"; tags are global step indices + 1, so they never need clearing again
-    const size_t gran_bytes = (2UL * c->resident_bands * 2 * p.nx + c->resident_bands) * sizeof(uint4);  // + one XCC-id granule per band
+    const size_t gran_bytes = resident_gran_bytes(c);
     HIP_TRY(LBM_FAILURE, hipMalloc(&sl.res_gran, gran_bytes));
     HIP_TRY(LBM_FAILURE, hipMemsetAsync(sl.res_gran, 0, gran_bytes, sl.compute));
     HIP_TRY(LBM_FAILURE, hipMalloc(&sl.res_part, (size_t)kResidentChunk * c->resident_bands * sizeof(float)));

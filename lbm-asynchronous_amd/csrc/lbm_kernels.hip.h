@@ -1519,7 +1519,6 @@ struct ResidentArgs {
   int poll_sleep;             // s_sleep argument (units of 64 clocks) between two looks at the halo granules
   int xcd_affinity;           // 1: seams inside one XCD use L2-resident stores (see resident_band); 0: sc1 everywhere
   int absent_band;            // tests: this band's workgroup returns at once, as if it had never been scheduled (-1: none)
-  int one_xcd;                // 1: the launch has 8 workgroups per band and only those dealt to the first XCD work
 #ifdef LBM_RESIDENT_PROFILE
   long long* prof;            // tools/resident_profile.sh: [band][8] shader-clock sums of the phases of a step
 #endif
@@ -1629,13 +1628,11 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
   static_assert(ROWS == 4 || ROWS == 2, "bands of four or two rows");
   constexpr int NE = (ROWS == 4) ? 10 : 4;  // wave-edge values per side
   const int x = threadIdx.x, lane = x & 63, wave = x >> 6, n_waves = blockDim.x >> 6;
-  const int bands = a.one_xcd ? (int)(gridDim.x >> 3) : (int)gridDim.x;
-  if (a.one_xcd && (blockIdx.x & 7) != 0) return;
+  const int bands = gridDim.x;
   // Workgroups are dealt to the 8 XCDs round-robin (observed, not promised): consecutive bands are given to
   // workgroups 8 apart, so that most seams join two bands on ONE XCD.  Speed only -- which seams really do is
   // established below from the hardware's own XCC id, and the protocol is correct for any placement.
-  const int b = a.one_xcd ? (int)(blockIdx.x >> 3)
-              : (a.xcd_affinity && (bands & 7) == 0) ? (int)(blockIdx.x & 7) * (bands >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int b = (a.xcd_affinity && (bands & 7) == 0) ? (int)(blockIdx.x & 7) * (bands >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const long ps = a.plane_stride;
   // wave-edge values: [parity][wave][side: 0 = lane 0's west-moving, 1 = lane 63's east-moving][NE used of 12]
   __shared__ __attribute__((aligned(16))) float edge[2][MAXT / 64][2][12];
