@@ -12,6 +12,7 @@
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
+#include <algorithm>
 
 #include <atomic>
 #include <condition_variable>
@@ -1166,6 +1167,16 @@ int run_resident(lbm_ctx* c, int n_steps) {
         double sum = 0, lo = 1e30, hi = 0;
         for (int b = 0; b < c->resident_bands; b++) { const double v = (double)h[b * 8 + i] / n; sum += v; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
         fprintf(stderr, "  %-20s %9.2f %9.2f %9.2f\n", phase[i], sum / c->resident_bands, lo, hi);
+      }
+      // the bands that wait least for their neighbours set the pace: who are they, and where does their time go?
+      std::vector<int> order(c->resident_bands);
+      for (int b = 0; b < c->resident_bands; b++) order[b] = b;
+      std::sort(order.begin(), order.end(), [&](int x, int y) { return h[x * 8 + 4] < h[y * 8 + 4]; });
+      for (int k = 0; k < 6 && k < c->resident_bands; k++) {
+        const int b = order[k];
+        fprintf(stderr, "  band %3d:", b);
+        for (int i = 0; i < 7; i++) fprintf(stderr, " %8.1f", (double)h[b * 8 + i] / n);
+        fprintf(stderr, "\n");
       }
     }
 #endif

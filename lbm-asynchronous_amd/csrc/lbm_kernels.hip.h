@@ -1237,7 +1237,11 @@ __global__ __launch_bounds__(64, NP == 1 ? (K > 2 ? 3 : (PREFETCH ? 2 : 4)) : 2)
   RowPull<C> nextp;
   if constexpr (PREFETCH) nextp = pull_row<C>(pa, r_next, x0);
 
-  for (int i = 0; i < n_iter; i++) {
+  // One row iteration.  WARM: the first 2 (K-1) iterations of a band, while the later stages have nothing to work on
+  // yet; the iterations after them run a copy of the body without those tests (every stage active: no merges of
+  // "relaxed" and "skipped" register sets, whose copies were 5 % of the steady state's vector instructions).
+  auto row_iteration = [&](auto warm_c, const int i) {
+    constexpr bool WARM = decltype(warm_c)::value;
     // ---- stage 1: step t on row r, pulled from memory -------------------------------------------
     const int r = r_next;
     r_next = r + 1;
@@ -1280,7 +1284,7 @@ __global__ __launch_bounds__(64, NP == 1 ? (K > 2 ? 3 : (PREFETCH ? 2 : 4)) : 2)
       WindowPk<NP>& w = win[s - 1];
       const int ring = (i & 1) * 3;
       f2 nxt[NP][kQ];
-      const bool active = (i >= 2 * s);
+      const bool active = WARM ? (i >= 2 * s) : true;
       if (active) {
         // planes of the window rows: 2,5,6 of row ro-1, 0,1,3 of row ro, and 4,7,8 of row ro+1 (= cur)
         f2 pl[kQ][NP];
@@ -1348,7 +1352,11 @@ __global__ __launch_bounds__(64, NP == 1 ? (K > 2 ? 3 : (PREFETCH ? 2 : 4)) : 2)
     stage(std::integral_constant<int, 1>{});
     if constexpr (K > 2) stage(std::integral_constant<int, 2>{});
     if constexpr (K > 3) stage(std::integral_constant<int, 3>{});
-  }
+  };
+  const int n_warm = min(n_iter, 2 * (K - 1));
+  int i = 0;
+  for (; i < n_warm; i++) row_iteration(std::true_type{}, i);
+  for (; i < n_iter; i++) row_iteration(std::false_type{}, i);
 
 #pragma unroll
   for (int s = 0; s < K; s++) {
