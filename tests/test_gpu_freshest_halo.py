@@ -95,7 +95,7 @@ def test_mixed_schedules_equal_the_model(lbm, oracle, monkeypatch, slabs, halo, 
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     np.testing.assert_allclose(got_av, (want_tot / np.float64((ob == 0).sum())).astype(np.float32), rtol=AV_RTOL)
     stale, _ = slab_model.run_slabs(oracle, lbm, p, ob, calls, slabs, lag=1, two_step=False, cells=cells)
-    assert not np.array_equal(got.view(np.uint32), stale.view(np.uint32))
+    assert np.array_equal(got.view(np.uint32), stale.view(np.uint32)) == (not (inner != 0).any())
     print(f"schedule (rows: slabs, columns: steps):\n{log.T}")
 
 
