@@ -100,6 +100,9 @@ typedef struct {
                             kernel (lattice in registers, up to this many timesteps per launch); single periodic slabs of
                             at most 1024 x 4*CUs cells */
   int    resident_min_steps;
+  int    resident_rows;      /* resident kernel: rows per band (4 or 2) ... */
+  int    resident_group;     /* ... bands per workgroup (1, 2 or 4) ... */
+  int    resident_one_xcd;   /* ... and 1 where the whole grid (at most 128 waves) runs on one XCD, one wave per SIMD */
 } lbm_info;
 
 /* ---- error handling -------------------------------------------------------------------- */

@@ -66,7 +66,8 @@ class _CInfo(ctypes.Structure):
                 ("world_size", ctypes.c_int), ("steps_per_launch", ctypes.c_int),
                 ("halo_mode", ctypes.c_int), ("band_rows", ctypes.c_int), ("lane_cells", ctypes.c_int),
                 ("nontemporal", ctypes.c_int), ("graph_steps", ctypes.c_int),
-                ("resident_steps", ctypes.c_int), ("resident_min_steps", ctypes.c_int)]
+                ("resident_steps", ctypes.c_int), ("resident_min_steps", ctypes.c_int),
+                ("resident_rows", ctypes.c_int), ("resident_group", ctypes.c_int), ("resident_one_xcd", ctypes.c_int)]
 
 
 class _CRcclStatus(ctypes.Structure):

@@ -365,6 +365,8 @@ struct lbm_ctx {
   int resident_bands = 0;           // its workgroups (bands of resident_rows rows)
   int resident_joint = 0;           // narrow grids: both pairs of a lane relaxed as one block behind the halo wait
   int resident_rows = 4;            // rows per band: 4, or 2 where the chip has CUs to spare (one pair per lane)
+  int resident_group = 1;           // bands per workgroup
+  int resident_one_xcd = 0;         // all workgroups on one XCD (8 x the workgroups launched, 7 of 8 leave at once)
   long long resident_timeout = 0;   // bound of one halo wait, wall-clock ticks
   bool resident_used = false;       // a launch is in flight / unchecked: lbm_sync reads its status
   int tile_steps = 0;               // > 0: single slab advanced by the LDS-tile kernel, this many steps per launch
@@ -1150,9 +1152,11 @@ int run_resident(lbm_ctx* c, int n_steps) {
     if (!prof_dev) HIP_TRY(LBM_FAILURE, hipMalloc(&prof_dev, 1024 * 8 * sizeof(long long)));
     a.prof = prof_dev;
 #endif
+    a.group = c->resident_group;
+    a.one_xcd = c->resident_one_xcd;
     void* args[] = {&a};
-    HIP_TRY(LBM_FAILURE, hipLaunchKernel(resident_kernel(c->p.nx, c->resident_rows, c->resident_joint), dim3(c->resident_bands),
-                                         dim3(c->p.nx), args, 0, sl.compute));
+    HIP_TRY(LBM_FAILURE, hipLaunchKernel(resident_kernel(c->p.nx, c->resident_rows, c->resident_joint),
+                                         dim3(c->resident_bands / a.group * (a.one_xcd ? 8 : 1)), dim3(c->p.nx * a.group), args, 0, sl.compute));
     hipLaunchKernelGGL(lbm::reduce_band_partials, dim3(n), dim3(64), 0, sl.compute, (const float*)sl.res_part,
                        c->resident_bands, sl.tot_u, c->steps_done + t);
     HIP_TRY(LBM_FAILURE, hipGetLastError());
@@ -1997,6 +2001,24 @@ lbm_ctx* create_common(const lbm_params* params, const ObstacleSource& obst, con
         c->resident_rows = rows;
         c->resident_bands = ny / rows;
         c->resident_joint = joint;
+        // Grids of at most 128 waves (two-row bands): everything on ONE XCD, one wave per SIMD -- workgroups of four
+        // waves (1, 2 or 4 bands side by side), at most one per CU of the XCD; 8 x the workgroups are launched and
+        // those not dealt to the first XCD leave at once.  Then no seam crosses the fabric (hand-off 0.29 instead of
+        // 0.63 us, tools/hop_flavours.hip): 128^2 1.10 vs 1.36 us per step, 64x128 1.06 vs 1.34, 128x64 1.05 vs 1.42
+        // (two bands per workgroup alone: no change; one XCD with two workgroups per CU: none either).
+        {
+          const int waves_per_band = nx / 64, cus_per_xcd = cus / 8;
+          int group = 1, one_xcd = 0;
+          if (rows == 2 && waves_per_band <= 4) {
+            for (int g = 1; g * waves_per_band <= 4 && !one_xcd; g *= 2)
+              if (c->resident_bands % g == 0 && c->resident_bands / g <= cus_per_xcd) { group = g; one_xcd = 1; }
+          }
+          one_xcd = env_int("LBM_RESIDENT_ONE_XCD", one_xcd) ? 1 : 0;
+          group = env_int("LBM_RESIDENT_GROUP", one_xcd ? group : 1);
+          if (group < 1 || c->resident_bands % group != 0 || nx * group > (nx > 512 ? 1024 : 512)) group = 1;
+          c->resident_group = group;
+          c->resident_one_xcd = one_xcd;
+        }
         // a launch costs about 20 us before its first step (lattice into registers, back out, reduce, status copy);
         // measured wall time of one lbm_run(n) + sync, per-pass kernels | resident (tools/resident_crossover.py):
         // 128^2 n = 4 24.5 | 27.0, n = 8 32.9 | 32.4, n = 16 50.0 | 44.4; 256^2 n = 4 28.8 | 28.4, n = 8 41.0 | 35.4;
@@ -2313,6 +2335,9 @@ int lbm_get_info(const lbm_ctx* c, lbm_info* out) {
   }
   out->resident_steps = c->resident ? kResidentChunk : 0;
   out->resident_min_steps = c->resident ? c->resident_min_steps : 0;
+  out->resident_rows = c->resident ? c->resident_rows : 0;
+  out->resident_group = c->resident ? c->resident_group : 0;
+  out->resident_one_xcd = c->resident ? c->resident_one_xcd : 0;
   return LBM_SUCCESS;
 }
 

@@ -1527,6 +1527,8 @@ struct ResidentArgs {
   int poll_sleep;             // s_sleep argument (units of 64 clocks) between two looks at the halo granules
   int xcd_affinity;           // 1: seams inside one XCD use L2-resident stores (see resident_band); 0: sc1 everywhere
   int absent_band;            // tests: this band's workgroup returns at once, as if it had never been scheduled (-1: none)
+  int group;                  // bands per workgroup (blockDim.x = group * nx)
+  int one_xcd;                // 1: the launch has 8 workgroups per working one and only those dealt to the first XCD work
 #ifdef LBM_RESIDENT_PROFILE
   long long* prof;            // tools/resident_profile.sh: [band][8] shader-clock sums of the phases of a step
 #endif
@@ -1635,12 +1637,18 @@ template <int MAXT, bool JOINT = false, int ROWS = 4>
 __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
   static_assert(ROWS == 4 || ROWS == 2, "bands of four or two rows");
   constexpr int NE = (ROWS == 4) ? 10 : 4;  // wave-edge values per side
-  const int x = threadIdx.x, lane = x & 63, wave = x >> 6, n_waves = blockDim.x >> 6;
-  const int bands = gridDim.x;
+  // a workgroup holds a.group bands side by side (1: the usual case; more where a band has fewer than four waves and
+  // the whole grid fits one XCD with one wave per SIMD, see a.one_xcd): `wave`, `n_waves` count inside the band,
+  // `wv` inside the workgroup
+  const int grp = (int)threadIdx.x / a.nx;
+  const int x = (int)threadIdx.x - grp * a.nx, lane = x & 63, wave = x >> 6, n_waves = a.nx >> 6, wv = (int)threadIdx.x >> 6, wv0 = wv - wave;
+  const int n_wgs = a.one_xcd ? (int)(gridDim.x >> 3) : (int)gridDim.x, wg = a.one_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  if (a.one_xcd && (blockIdx.x & 7) != 0) return;
+  const int bands = n_wgs * a.group;
   // Workgroups are dealt to the 8 XCDs round-robin (observed, not promised): consecutive bands are given to
   // workgroups 8 apart, so that most seams join two bands on ONE XCD.  Speed only -- which seams really do is
   // established below from the hardware's own XCC id, and the protocol is correct for any placement.
-  const int b = (a.xcd_affinity && (bands & 7) == 0) ? (int)(blockIdx.x & 7) * (bands >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int b = a.group * ((!a.one_xcd && a.xcd_affinity && (n_wgs & 7) == 0) ? (wg & 7) * (n_wgs >> 3) + (wg >> 3) : wg) + grp;
   const long ps = a.plane_stride;
   // wave-edge values: [parity][wave][side: 0 = lane 0's west-moving, 1 = lane 63's east-moving][NE used of 12]
   __shared__ __attribute__((aligned(16))) float edge[2][MAXT / 64][2][12];
@@ -1709,7 +1717,7 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
       __builtin_amdgcn_s_sleep(1);
     }
   }
-  const int west_wave = (wave == 0) ? n_waves - 1 : wave - 1, east_wave = (wave == n_waves - 1) ? 0 : wave + 1;
+  const int west_wave = wv0 + ((wave == 0) ? n_waves - 1 : wave - 1), east_wave = wv0 + ((wave == n_waves - 1) ? 0 : wave + 1);
 
   // publish the edge rows of a state: step s of this launch reads what was published with its tag into its slot
   auto publish = [&](int s) {
@@ -1735,7 +1743,7 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
     // ROWS = 4: east-moving (from lane 63) 1 of rows 0..3, 5 of rows 0..2, 8 of rows 1..3; west-moving (from lane 0) 3, 6, 7
     // ROWS = 2: east-moving 1 of rows 0, 1, 5 of row 0, 8 of row 1; west-moving 3 of rows 0, 1, 6 of row 0, 7 of row 1
     if (lane == 63) {
-      float* e = edge[slot][wave][1];
+      float* e = edge[slot][wv][1];
       if constexpr (ROWS == 4) {
         e[0] = re[1].x; e[1] = ri[1].x; e[2] = ri[1].y; e[3] = re[1].y;
         e[4] = re[5].x; e[5] = ri[5].x; e[6] = ri[5].y; e[7] = ri[8].x;
@@ -1745,7 +1753,7 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
       }
     }
     if (lane == 0) {
-      float* e = edge[slot][wave][0];
+      float* e = edge[slot][wv][0];
       if constexpr (ROWS == 4) {
         e[0] = re[3].x; e[1] = ri[3].x; e[2] = ri[3].y; e[3] = re[3].y;
         e[4] = re[6].x; e[5] = ri[6].x; e[6] = ri[6].y; e[7] = ri[7].x;
@@ -1759,7 +1767,7 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
     RESIDENT_PROF(1);  // barrier
     if (s > 0 && wave == 0) {
       // the per-wave sums of the previous step, written before this barrier: one partial per band and step
-      const float v = row16_sum_dpp((lane < n_waves) ? wave_part[slot ^ 1][lane] : 0.f);
+      const float v = row16_sum_dpp((lane < n_waves) ? wave_part[slot ^ 1][wv0 + lane] : 0.f);
       if (lane == 0) a.partials[(long)(s - 1) * bands + b] = v;
     }
     float W[NE], E[NE];
@@ -1878,7 +1886,7 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
     if (s + 1 < a.n_steps && alive) publish(s + 1);
     // blocked cells report 0; sum over the wave, one partial per wave into LDS (summed after the next barrier)
     const float tot = wave_sum_dpp(sum);
-    if (lane == 63) wave_part[slot][wave] = tot;
+    if (lane == 63) wave_part[slot][wv] = tot;
     RESIDENT_PROF(6);  // publish, wave sum
     // (a wave that gave up leaves the loop alone: the hardware barrier counts only waves that have not ended, and
     // the others find *status set in their next spin)
@@ -1890,7 +1898,7 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
 #endif
   __syncthreads();
   if (a.n_steps > 0 && wave == 0) {
-    const float v = row16_sum_dpp((lane < n_waves) ? wave_part[(a.n_steps - 1) & 1][lane] : 0.f);
+    const float v = row16_sum_dpp((lane < n_waves) ? wave_part[(a.n_steps - 1) & 1][wv0 + lane] : 0.f);
     if (lane == 0) a.partials[(long)(a.n_steps - 1) * bands + b] = v;
   }
   float* out = a.dst + (long)(ROWS * b) * a.row_pitch + x;

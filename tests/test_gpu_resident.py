@@ -45,10 +45,14 @@ def test_resident_reference_datasets_bitwise(lbm, oracle, datasets, monkeypatch,
                                        (128, 64, {"LBM_RESIDENT_XCD": "0"}), (192, 36, {}),
                                        (128, 128, {"LBM_RESIDENT_ROWS": "4"}), (256, 256, {"LBM_RESIDENT_ROWS": "2"}),
                                        (64, 6, {}), (320, 30, {}), (512, 512, {"LBM_RESIDENT_ROWS": "2"}),
-                                       (1024, 512, {"LBM_RESIDENT_ROWS": "2"}), (448, 250, {"LBM_RESIDENT_ROWS": "2", "LBM_RESIDENT_XCD": "0"})])
+                                       (1024, 512, {"LBM_RESIDENT_ROWS": "2"}), (448, 250, {"LBM_RESIDENT_ROWS": "2", "LBM_RESIDENT_XCD": "0"}),
+                                       (128, 128, {}), (128, 128, {"LBM_RESIDENT_ONE_XCD": "0"}), (128, 128, {"LBM_RESIDENT_ONE_XCD": "0", "LBM_RESIDENT_GROUP": "4"}),
+                                       (64, 64, {}), (64, 256, {}), (64, 64, {"LBM_RESIDENT_GROUP": "8"}), (256, 64, {}), (256, 64, {"LBM_RESIDENT_GROUP": "2"}),
+                                       (128, 64, {"LBM_RESIDENT_GROUP": "2", "LBM_RESIDENT_XCD": "0"}), (64, 12, {"LBM_RESIDENT_GROUP": "2"})])
 def test_resident_random_lattices_bitwise(lbm, oracle, monkeypatch, nx, ny, env):
     """Random lattices with random obstacles (also on the seam rows and at the wave edges), both periodic wraps live,
-    widths of 1 to 16 waves -- full and partly filled workgroups --, 2 to 256 bands of four or two rows; every call resident.  Both orders
+    widths of 1 to 16 waves -- full and partly filled workgroups --, 2 to 256 bands of four or two rows, 1 to 8 bands per
+    workgroup, on one XCD (the default up to 128 waves) or dealt over all eight; every call resident.  Both orders
     of a step (interior pair before the halo wait / both pairs together behind it), seams kept in an XCD's L2 where
     both bands run on it and written through everywhere (band counts that are and are not multiples of 8)."""
     monkeypatch.setenv("LBM_RESIDENT_MIN_STEPS", "1")
@@ -114,6 +118,15 @@ def test_resident_policy(lbm, monkeypatch):
     assert not resident(1024, 1022)                    # 1024 wide: four-row bands only
     assert not resident(1024, 2048)                    # 512 bands: more than the device has CUs
     assert not resident(128, 128, LBM_FUSE2="1") and not resident(128, 128, LBM_TILE_STEPS="4")
+
+    def placement(nx, ny):
+        with lbm.Engine(lbm.Params(nx, ny, 4, 10, 0.1, 0.005, 1.85), np.zeros((ny, nx), dtype=np.int32), None) as eng:
+            i = eng.info()
+            return i["resident_rows"], i["resident_group"], i["resident_one_xcd"]
+    # up to 128 waves: one XCD, workgroups of four waves, at most 32 of them
+    assert placement(128, 128) == (2, 2, 1) and placement(64, 128) == (2, 2, 1) and placement(64, 256) == (2, 4, 1)
+    assert placement(256, 64) == (2, 1, 1) and placement(128, 64) == (2, 1, 1)
+    assert placement(128, 256) == (2, 1, 0) and placement(256, 256) == (2, 1, 0) and placement(1024, 1024) == (4, 1, 0)
     assert resident(128, 128, LBM_FUSE2="1", LBM_RESIDENT="1") and not resident(128, 128, LBM_RESIDENT="0")
 
 
