@@ -135,3 +135,22 @@ def test_mode_switches(lbm, oracle, monkeypatch):
         assert np.array_equal(eng.cells().view(np.uint32), ref.view(np.uint32))
         with pytest.raises(lbm.LbmError, match="unknown mode"):
             lbm._check(eng.lib, eng.lib.lbm_set_halo_mode(eng.handle, 7))
+
+
+def test_hosted_exchange_refuses_the_mode(lbm, monkeypatch):
+    """The MPI-callback transport blocks the host in every exchange: there is nothing to poll.  Asking for the mode there
+    is an error at once, not a silent synchronous run."""
+    monkeypatch.setenv("LBM_FORCE_HALO", "1")
+    p, ob, cells = random_case(lbm, 128, 24, 7, walls=False)
+
+    def exchange(plan, bufs):       # a ring of one: what goes north comes back as the south halo and vice versa
+        bufs[2][:] = bufs[0]
+        bufs[3][:] = bufs[1]
+
+    def allreduce(values):
+        pass
+    with lbm.Engine(p, ob, cells, rank=0, world_size=1, device=0, host_comm=(exchange, allreduce)) as eng:
+        with pytest.raises(lbm.LbmError, match="hosted exchange"):
+            eng.set_halo_mode("freshest")
+        eng.run(3)                  # the context is still good, in the synchronous mode
+        assert eng.info()["halo_mode"] == lbm.HALO_SYNC
