@@ -1141,7 +1141,6 @@ int run_resident(lbm_ctx* c, int n_steps) {
     a.gran = sl.res_gran;
     a.gran_bytes = (unsigned)resident_gran_bytes(c);
     a.xcd_affinity = env_int("LBM_RESIDENT_XCD", 1) ? 1 : 0;
-    a.poll_sleep = env_int("LBM_RESIDENT_SLEEP", c->p.nx > 512 ? 4 : 1);
     a.epoch0 = (unsigned)(c->steps_done + t);
     a.partials = sl.res_part;
     a.status = sl.res_status;

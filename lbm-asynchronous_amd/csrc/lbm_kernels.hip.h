@@ -1524,7 +1524,6 @@ struct ResidentArgs {
   float* partials;            // partials[s * bands + b] = sum |u| over band b after step s
   int* status;                // 0, or kResidentTimeout once any workgroup gave up waiting
   long long timeout_ticks;    // bound of one halo wait in wall_clock64() ticks (100 MHz)
-  int poll_sleep;             // s_sleep argument (units of 64 clocks) between two looks at the halo granules
   int xcd_affinity;           // 1: seams inside one XCD use L2-resident stores (see resident_band); 0: sc1 everywhere
   int absent_band;            // tests: this band's workgroup returns at once, as if it had never been scheduled (-1: none)
   int group;                  // bands per workgroup (blockDim.x = group * nx)
@@ -1850,13 +1849,9 @@ __global__ __launch_bounds__(MAXT) void resident_band(const ResidentArgs a) {
         }
         // how long to stay off the issue ports before asking again: short where the wave sits alone on its SIMD
         // (latency is everything), long where three other waves want the slots (a poll is ~25 instructions)
-        switch (a.poll_sleep) {
-          case 16: __builtin_amdgcn_s_sleep(16); break;
-          case 8: __builtin_amdgcn_s_sleep(8); break;
-          case 4: __builtin_amdgcn_s_sleep(4); break;
-          case 2: __builtin_amdgcn_s_sleep(2); break;
-          default: __builtin_amdgcn_s_sleep(1); break;
-        }
+        // (a compile-time choice: measured over 0 ... 16 at every size the value hardly matters, and as a run-time switch
+        // it cost a dozen scalar instructions and four branches per look)
+        __builtin_amdgcn_s_sleep(MAXT > 512 ? 4 : 1);
         asm volatile("" ::: "memory");  // the loads must be issued again in every spin
         cs = granule_load(grsrc, gs + (unsigned)x * 16u);
         cn = granule_load(grsrc, gn + (unsigned)x * 16u);
